@@ -1,0 +1,138 @@
+/*
+ * yabpe.h -- C ABI of the MI355X-native BPE training hot path (libyabpe.so).
+ *
+ * The reference (DreamOneX/yet-another-bpe) is pure Python and has no FFI: its seam for this path is the
+ * method BBPETrainer._merge_loop (src/yet_another_bpe/trainer.py:216-302), fed by train() (:63-92).
+ * These entry points are what a binding for that method needs; each one names the reference lines whose
+ * RESULT it reproduces.  Plain pointers and sizes only (no torch / numpy types); every pointer the caller
+ * passes stays owned by the caller; the library owns only its opaque context and the device buffers it
+ * hands out through yabpe_synth_generate().
+ *
+ * All functions return 0 (YABPE_OK) or a negative error code; yabpe_last_error() gives the message.
+ * A context is bound to one GPU and must not be used from two threads at once.
+ * There is NO CPU fallback: without a usable gfx950 device yabpe_create() fails with YABPE_E_NODEVICE.
+ */
+#ifndef YABPE_H
+#define YABPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YABPE_ABI_VERSION 1
+
+enum {
+    YABPE_OK = 0,
+    YABPE_E_INVALID = -1,  /* bad argument / call order */
+    YABPE_E_NODEVICE = -2, /* no HIP device */
+    YABPE_E_HIP = -3,      /* HIP runtime error (message has the call) */
+    YABPE_E_CAPACITY = -4, /* a documented limit was hit (token ids are u16: at most 65534 tokens) */
+    YABPE_E_INTERNAL = -5, /* device-side invariant violated */
+    YABPE_E_COMM = -6      /* RCCL error */
+};
+
+/* yabpe_load_words flags */
+#define YABPE_LOAD_DEDUP 0x1u /* pool equal words on the device first (trainer.py:221-225) */
+
+typedef struct yabpe_ctx yabpe_ctx;
+
+/* Library / device ---------------------------------------------------------------------------------- */
+int yabpe_abi_version(void);
+int yabpe_device_count(void);
+
+/* Creates a context on HIP device `device_id`.  One context per _merge_loop call (or reuse via yabpe_reset). */
+int yabpe_create(yabpe_ctx **out, int device_id);
+void yabpe_destroy(yabpe_ctx *ctx);
+/* Message of the last error on this context (ctx == NULL: of the last failed yabpe_create). Never NULL. */
+const char *yabpe_last_error(const yabpe_ctx *ctx);
+
+/* Tunables by name (see DESIGN.md "Tunables"): "check_interval", "recount_every", "retile_frac",
+   "apply_blocks", "event_sample", "table_min_log2", "verify" ... */
+int yabpe_set_option(yabpe_ctx *ctx, const char *name, int64_t value);
+
+/* Base vocabulary ------------------------------------------------------------------------------------
+ * Result of _init_base_vocab (trainer.py:119-134): ids 0..n_tokens-1, token i = tok_bytes[tok_off[i]..tok_off[i+1]).
+ * The first 256 entries must be the single bytes 0..255 in order (trainer.py:123-125).  The host computes the
+ * list (dedup rule of :130 included); the device needs the bytes for the byte-lexicographic tie-break (:246)
+ * and for "merged not in vocab" (:298). */
+int yabpe_set_vocab(yabpe_ctx *ctx, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tokens);
+
+/* Corpus ---------------------------------------------------------------------------------------------
+ * The `sequences` argument of _merge_loop (trainer.py:216) as flat buffers: word i = bytes[word_off[i]..word_off[i+1]).
+ * word_freq == NULL means every word counts once (flat layout: every occurrence resident in HBM).
+ * With word_freq the caller has already pooled equal words (trainer.py:221-225) and passes their counts.
+ * Pointers may be host or device memory (detected); device buffers are read in place, host buffers are staged. */
+int yabpe_load_words(yabpe_ctx *ctx, const uint8_t *bytes, const uint64_t *word_off, const uint64_t *word_freq,
+                     uint64_t n_words, uint32_t flags);
+
+/* Merge loop -----------------------------------------------------------------------------------------
+ * Runs trainer.py:238-300: at most `num_merges` iterations (the host computes max(0, vocab_size - len(vocab)),
+ * :238), stops early when no pair is left (:242-243) or the best count < min_frequency (:247-248).
+ * Outputs, one entry per merge in selection order (arrays of capacity num_merges, may be NULL):
+ *   out_left/out_right   ids of the merged pair            (merges.append(best_pair), :296)
+ *   out_merged           id of left+right: a fresh id, or the existing id when those bytes are already a
+ *                        token (no id consumed, :298-300)
+ *   out_count            the pair's count when it was selected
+ * May be called again to continue training with more merges. */
+int yabpe_train(yabpe_ctx *ctx, uint32_t num_merges, uint64_t min_frequency, uint32_t *out_left,
+                uint32_t *out_right, uint32_t *out_merged, uint64_t *out_count, uint32_t *out_n_merges);
+
+/* Token bytes after training: token id -> bytes (vocab of trainer.py:302, inverted). */
+int yabpe_n_tokens(yabpe_ctx *ctx, uint32_t *out_n_tokens);
+int yabpe_token_bytes(yabpe_ctx *ctx, uint32_t id, uint8_t *out, uint32_t cap, uint32_t *out_len);
+
+/* Measurement ---------------------------------------------------------------------------------------- */
+typedef struct yabpe_stats_t {
+    uint64_t n_words;          /* W: resident words (after optional dedup) */
+    uint64_t n_words_input;    /* words passed to yabpe_load_words */
+    uint64_t n_long_words;     /* words handled by the long-word path */
+    uint64_t tokens_initial;   /* T_0 */
+    uint64_t tokens_now;       /* T_i = T_0 - sum of merged sites */
+    uint64_t merges_done;
+    uint64_t n_tiles;
+    uint64_t live_slots;       /* u16 slots the apply kernel currently reads */
+    uint64_t table_capacity;
+    uint64_t table_entries;
+    uint64_t retiles, table_rebuilds;
+    double load_ms;            /* yabpe_load_words device time */
+    double train_ms;           /* device time of all yabpe_train calls (event-timed) */
+    double apply_ms_sampled;   /* sum of event-timed apply launches ("event_sample") */
+    uint64_t apply_launches_sampled;
+    uint64_t apply_algo_bytes_sampled;   /* sum of 2*(T_i + W) over the sampled launches */
+    uint64_t apply_actual_bytes_sampled; /* sum of 2*live_slots over the sampled launches */
+    uint64_t algo_bytes_total;           /* sum over all iterations of 2*(T_i + W) */
+} yabpe_stats_t;
+int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
+/* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */
+int yabpe_iter_log(yabpe_ctx *ctx, uint64_t *out_sites, uint64_t *out_live_slots, uint32_t cap, uint32_t *out_n);
+
+/* Debug / self-check: recount every pair from the token stream into a scratch table and compare with the
+   incrementally maintained table.  *out_mismatches = number of differing keys. */
+int yabpe_verify_table(yabpe_ctx *ctx, uint64_t *out_mismatches);
+/* Debug: decode the resident token stream back to bytes and return an order-independent checksum over
+   (word bytes, segmentation) plus the number of words/tokens it saw. */
+int yabpe_stream_checksum(yabpe_ctx *ctx, uint64_t *out_sum, uint64_t *out_words, uint64_t *out_tokens);
+
+/* Synthetic corpus of SURVEY.md 8(d), generated on the device (bit-identical to yet_another_bpe/synth.py).
+   Returns device pointers owned by the library (freed by yabpe_synth_free or yabpe_destroy). */
+int yabpe_synth_generate(yabpe_ctx *ctx, uint64_t target_bytes, uint32_t n_types, uint64_t seed,
+                         const uint8_t *alphabet, uint32_t alphabet_len, int space_prefix,
+                         uint8_t **out_dev_bytes, uint64_t **out_dev_off, uint64_t *out_n_words, uint64_t *out_n_bytes);
+int yabpe_synth_free(yabpe_ctx *ctx);
+/* Copy `n` bytes device->host / host->device (for fixtures and the CPU-baseline sample). */
+int yabpe_memcpy_d2h(yabpe_ctx *ctx, void *dst_host, const void *src_dev, uint64_t n);
+
+/* Multi-GPU (one process per GPU; words are sharded by the caller) -----------------
+ * Every rank holds its shard of the words and a replica of the pair table.  After each apply pass the ranks
+ * exchange their aggregated (pair, delta) records with one RCCL all-gather and apply all of them.
+ * unique_id: the 128-byte ncclUniqueId produced by yabpe_comm_unique_id on rank 0 and broadcast by the caller. */
+int yabpe_comm_unique_id(uint8_t out_id[128]);
+int yabpe_comm_init(yabpe_ctx *ctx, int rank, int n_ranks, const uint8_t unique_id[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YABPE_H */
