@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- BPE training hot path on MI355X: merges/s (+ corpus bytes/s) to 32k merges on the 1 GiB
+synthetic byte corpus of SURVEY.md 8(d) config 3, with the apply kernel's HBM roofline and a CPU baseline.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE whole training job: words already resident in HBM (flat u8 bytes + u64 offsets) ->
+tile build + initial pair count -> `merges` merge iterations.  value = merges completed / wall time of the
+K timed steps (max over ranks).  N > 1: the same 1 GiB corpus is word-sharded over the ranks (strong scaling).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+for p in (REPO, REPO / "yet-another-bpe_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(ctx, pb, po, n_words, n_bytes, merges, budget_bytes, specials):
+    """C port of the reference algorithm (oracle/), 1 core, on the first `budget_bytes` of the same corpus."""
+    import numpy as np
+
+    from oracle import oracle
+
+    # number of leading words whose bytes fit the budget
+    off_all = ctx.d2h(po, min(n_words + 1, budget_bytes // 2 + 2) * 8, dtype=np.uint64)
+    k = int(np.searchsorted(off_all, budget_bytes, side="right")) - 1
+    k = max(1, min(k, len(off_all) - 1))
+    off = off_all[: k + 1].copy()
+    flat = ctx.d2h(pb, int(off[-1]))
+    t0 = time.time()
+    vocab, mg, info = oracle.train_flat(flat, off, 257 + merges, 1, specials, return_ids=True)
+    dt = time.time() - t0
+    return {
+        "value": round(len(mg) / dt, 2), "unit": "merges/s", "cores": 1, "kind": "port",
+        "sample": f"first {int(off[-1])} bytes ({k} words, {info['unique_words']} unique) of the same corpus, "
+                  f"{len(mg)} merges in {dt:.1f} s; C port of the reference's incremental algorithm (oracle/bpe_oracle.c); "
+                  f"host has {os.cpu_count()} cores",
+        "corpus_bytes_per_sec": round(int(off[-1]) / dt, 1),
+    }, (flat, off, mg)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--target-mib", type=int, default=1024)
+    ap.add_argument("--merges", type=int, default=32000)
+    ap.add_argument("--event-sample", type=int, default=16, help="time every Nth apply launch with HIP events (0 = off)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dedup-line", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from yet_another_bpe import _native, synth
+
+    specials = ["<|endoftext|>"]
+    base = [bytes([b]) for b in range(256)] + [b"<|endoftext|>"]
+    spec = synth.SynthSpec.config3(args.target_mib << 20)
+
+    gen = _native.Context(local_rank)
+    t0 = time.time()
+    pb, po, n_words, n_bytes = gen.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
+    log(f"[rank {rank}] corpus on device: {n_bytes} bytes, {n_words} words ({time.time()-t0:.2f} s)")
+
+    if world > 1:
+        from yet_another_bpe import distributed as ydist
+
+        runner = ydist.ShardedRunner(gen, pb, po, n_words, n_bytes, base, rank, world, local_rank)
+    else:
+        runner = None
+
+    def one_job(dedup: bool, event_sample: int):
+        if runner is not None:
+            return runner.run(args.merges, 1, dedup=dedup, event_sample=event_sample)
+        with _native.Context(local_rank) as ctx:
+            ctx.set_option("event_sample", event_sample)
+            ctx.set_vocab(base)
+            ctx.load_words_ptr(pb, po, n_words, dedup=dedup)
+            left, right, merged, count = ctx.train(args.merges, 1)
+            return {"n_merges": len(left), "stats": ctx.stats(), "left": left, "right": right, "merged": merged}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # code-object load + allocator warm-up on a tiny job (not a step)
+    with _native.Context(local_rank) as wctx:
+        import numpy as np
+
+        f, o = synth.generate(synth.SynthSpec(64 << 10, 1000, 5, b"abcdef", True))
+        wctx.set_vocab(base)
+        wctx.load_words(f, o)
+        wctx.train(20, 1)
+
+    for _ in range(args.warmup):
+        one_job(False, 0)
+    barrier()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = one_job(False, args.event_sample)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = res["stats"]
+    n_merges = res["n_merges"]
+    out = {
+        "metric": "merges_per_sec", "value": round(args.steps * n_merges / elapsed, 2), "unit": "merges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": f"{args.target_mib} MiB synthetic byte corpus (SURVEY 8d config 3: 256-value alphabet, 1M Zipf types, seed 3), "
+                               f"{args.merges} merges, min_frequency 1, flat layout (every word occurrence resident), "
+                               f"{'word-sharded over %d GPUs' % world if world > 1 else '1 GPU'}",
+                   "corpus_bytes": n_bytes, "words": n_words, "merges": n_merges},
+        "corpus_bytes_per_sec": round(args.steps * n_bytes / elapsed, 1),
+        "device_ms": {"load_tiles_and_initial_count": round(st["load_ms"], 2), "merge_loop": round(st["train_ms"], 2)},
+        "stream": {"tokens_initial": st["tokens_initial"], "tokens_final": st["tokens_now"], "n_tiles": st["n_tiles"],
+                   "live_slots_final": st["live_slots"], "retiles": st["retiles"], "table_entries": st["table_entries"],
+                   "table_capacity": st["table_capacity"], "table_rebuilds": st["table_rebuilds"], "long_words": st["n_long_words"]},
+    }
+    if st["apply_launches_sampled"]:
+        secs = st["apply_ms_sampled"] / 1000.0
+        achieved = st["apply_algo_bytes_sampled"] / secs / 1e9
+        out["roofline"] = {
+            "kernel": "k_apply<flat>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches_timed": st["apply_launches_sampled"],
+            "avg_launch_us": round(1e6 * secs / st["apply_launches_sampled"], 2),
+            "algo_bytes_per_launch": st["apply_algo_bytes_sampled"] // st["apply_launches_sampled"],
+            "actual_stream_bytes_per_launch": st["apply_actual_bytes_sampled"] // st["apply_launches_sampled"],
+            "actual_stream_GBps": round(st["apply_actual_bytes_sampled"] / secs / 1e9, 1),
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4),
+            "note": "achieved = sum 2*(T_i+W) over the event-timed launches / their summed duration (SURVEY 8d); "
+                    "traffic: see profiles/ (PMC passes are separate rocprofv3 runs)",
+        }
+    if rank == 0 and not args.no_dedup_line and world == 1:
+        t1 = time.perf_counter()
+        rd = one_job(True, 0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        same = bool((rd["left"] == res["left"]).all() and (rd["right"] == res["right"]).all()) if rd["n_merges"] == n_merges else False
+        out["dedup_layout"] = {"merges_per_sec": round(rd["n_merges"] / dt, 2), "seconds": round(dt, 3),
+                               "unique_words": rd["stats"]["n_words"], "same_merges_as_flat": same,
+                               "device_ms": {"dedup_load_count": round(rd["stats"]["load_ms"], 2), "merge_loop": round(rd["stats"]["train_ms"], 2)}}
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, (cflat, coff, cmg) = cpu_baseline(gen, pb, po, n_words, n_bytes, args.merges, args.cpu_sample_mib << 20, specials)
+        out["cpu_baseline"] = cb
+    gen.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

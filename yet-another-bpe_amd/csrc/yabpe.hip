@@ -1,0 +1,935 @@
+// yabpe.hip -- C ABI (include/yabpe.h) over the HIP kernels in yabpe_kernels.h / yabpe_aux_kernels.h.
+// Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC yabpe.hip -o libyabpe.so
+//
+// Host control flow of yabpe_train (reference trainer.py:238-300): per merge the host enqueues
+//   k_argmax_partial -> k_select -> k_rank_update -> k_apply (+ k_apply_long)
+// on one stream with NO host round trip; every kernel reads the current merge / stop flags from DevState
+// in HBM.  The host looks at DevState every `check_interval` merges to stop early (done), to service a
+// halt (grow + recount the pair table) and to retile the shrinking token stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/yabpe.h"
+#include "yabpe_kernels.h"
+#include "yabpe_aux_kernels.h"
+
+using namespace yb;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t e0, e1;
+    uint32_t iter_rel;
+};
+
+}  // namespace
+
+struct yabpe_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, int64_t> opt;
+
+    // vocab
+    bool have_vocab = false;
+    uint32_t base_tokens = 0;
+    TokTable tt{};
+    // corpus
+    bool have_words = false;
+    bool weighted = false;
+    uint64_t n_words = 0, n_words_input = 0, tokens_initial = 0;
+    uint32_t n_tiles = 0;
+    uint16_t *tiles = nullptr, *tiles_alt = nullptr;
+    uint32_t tiles_cap = 0, tiles_alt_cap = 0;  // capacities in tiles
+    uint32_t *tile_len = nullptr, *tile_len_alt = nullptr;
+    uint32_t *tile_wbase = nullptr, *tile_wbase_alt = nullptr;
+    uint32_t *wfreq = nullptr;
+    // long words
+    uint32_t n_long = 0;
+    uint16_t *long_tok = nullptr;
+    unsigned long long *long_off = nullptr;
+    uint32_t *long_len = nullptr, *long_freq = nullptr;
+    uint64_t long_tokens = 0;
+    // pair table
+    PairTable table{};
+    uint64_t table_cap = 0;
+    // state
+    DevState *st = nullptr;
+    DevState *st_host = nullptr;  // pinned
+    Best *partials = nullptr;
+    uint32_t n_partials = 0;
+    // records of the last train call
+    uint32_t rec_cap = 0, rec_n = 0;
+    uint32_t *rec_left = nullptr, *rec_right = nullptr, *rec_merged = nullptr;
+    unsigned long long *rec_count = nullptr, *rec_sites = nullptr, *rec_live = nullptr;
+    std::vector<uint64_t> log_sites, log_live;
+    // stats
+    yabpe_stats_t stats{};
+    std::vector<EventPair> events;
+    // synth buffers
+    std::vector<void *> synth_bufs;
+    // misc device scratch
+    unsigned long long *scratch64 = nullptr;  // 8 x u64
+};
+
+namespace {
+
+int fail(yabpe_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail((c), YABPE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+template <class T>
+int dmalloc(yabpe_ctx *c, T **p, uint64_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(c, hipMalloc((void **)p, n * sizeof(T)));
+    return 0;
+}
+#define TRY(x)               \
+    do {                     \
+        int r__ = (x);       \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+void dfree(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+int64_t optv(yabpe_ctx *c, const char *k, int64_t dflt) {
+    auto it = c->opt.find(k);
+    return it == c->opt.end() ? dflt : it->second;
+}
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+inline uint32_t cdiv64(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int fill_u16(yabpe_ctx *c, uint16_t *p, uint64_t n, uint16_t v) {
+    if (!n) return 0;
+    uint64_t th = (n + 7) / 8;
+    hipLaunchKernelGGL(k_fill_u16, dim3(cdiv64(th, 256)), dim3(256), 0, c->stream, p, (unsigned long long)n, v);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int fill_u32(yabpe_ctx *c, uint32_t *p, uint64_t n, uint32_t v) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv64(n, 256)), dim3(256), 0, c->stream, p, (unsigned long long)n, v);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int state_pull(yabpe_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->st_host, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int state_push(yabpe_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->st, c->st_host, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- pair table
+void table_free(PairTable &t) {
+    dfree(t.keys);
+    dfree(t.cnt);
+    t.keys = nullptr;
+    t.cnt = nullptr;
+}
+
+int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
+    TRY(dmalloc(c, &t.keys, cap));
+    TRY(dmalloc(c, &t.cnt, cap));
+    t.mask = (uint32_t)(cap - 1);
+    t.max_probe = (uint32_t)std::min<uint64_t>(cap, 2048);
+    t.entries = entries_ctr;
+    HIPCHK(c, hipMemsetAsync(t.keys, 0xFF, cap * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(unsigned long long), c->stream));
+    return 0;
+}
+
+uint32_t count_grid(yabpe_ctx *c) {
+    uint32_t want = (c->n_tiles + WPB - 1) / WPB;
+    uint32_t cap = (uint32_t)optv(c, "apply_blocks", (int64_t)c->n_cu * 5);
+    return std::max(1u, std::min(want, cap));
+}
+
+// full recount of the resident stream into `t` (zeroed by the caller)
+int launch_count(yabpe_ctx *c, PairTable t) {
+    if (c->n_tiles) {
+        CountParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, t, c->st};
+        if (c->weighted)
+            hipLaunchKernelGGL(k_count<true>, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
+        else
+            hipLaunchKernelGGL(k_count<false>, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (c->n_long) {
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st};
+        hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+
+// (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/4.
+int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
+    uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        table_free(c->table);
+        HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, sizeof(uint32_t), c->stream));
+        TRY(table_alloc(c, c->table, cap, &c->st->table_entries));
+        c->table_cap = cap;
+        TRY(launch_count(c, c->table));
+        TRY(state_pull(c));
+        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 4 <= cap) {
+            c->stats.table_rebuilds++;
+            return 0;
+        }
+        cap *= (c->st_host->halt_req != 0 || c->st_host->table_entries * 2 > cap) ? 4 : 2;
+        if (cap > (1ull << 31)) break;
+    }
+    return fail(c, YABPE_E_CAPACITY, "pair table does not fit (more than 2^29 distinct pairs)");
+}
+
+int refresh_live_slots(yabpe_ctx *c) {
+    HIPCHK(c, hipMemsetAsync(&c->scratch64[0], 0, 8, c->stream));
+    if (c->n_tiles) {
+        hipLaunchKernelGGL(k_sum_u32, dim3(std::min<uint32_t>(1024, cdiv64(c->n_tiles, BLOCK))), dim3(BLOCK), 0, c->stream,
+                           c->tile_len, (unsigned long long)c->n_tiles, &c->scratch64[0]);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(&c->st->live_slots, &c->scratch64[0], 8, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+void free_corpus(yabpe_ctx *c) {
+    dfree(c->tiles); dfree(c->tiles_alt); dfree(c->tile_len); dfree(c->tile_len_alt);
+    dfree(c->tile_wbase); dfree(c->tile_wbase_alt); dfree(c->wfreq);
+    dfree(c->long_tok); dfree(c->long_off); dfree(c->long_len); dfree(c->long_freq);
+    c->tiles = c->tiles_alt = nullptr;
+    c->tile_len = c->tile_len_alt = c->tile_wbase = c->tile_wbase_alt = c->wfreq = nullptr;
+    c->long_tok = nullptr; c->long_off = nullptr; c->long_len = c->long_freq = nullptr;
+    c->n_long = 0; c->n_tiles = 0;
+    table_free(c->table);
+    c->have_words = false;
+}
+
+void free_records(yabpe_ctx *c) {
+    dfree(c->rec_left); dfree(c->rec_right); dfree(c->rec_merged);
+    dfree(c->rec_count); dfree(c->rec_sites); dfree(c->rec_live);
+    c->rec_left = c->rec_right = c->rec_merged = nullptr;
+    c->rec_count = c->rec_sites = c->rec_live = nullptr;
+    c->rec_cap = 0;
+}
+
+
+// Repack the live words of the flat layout into fresh, densely filled tiles (drops dead/empty words and PAD).
+// The apply kernel reads tile prefixes only, so this is what keeps its traffic proportional to live tokens.
+int retile_flat(yabpe_ctx *c) {
+    if (c->n_tiles == 0) return 0;
+    uint32_t *kept = nullptr;
+    unsigned long long *base = nullptr;
+    TRY(dmalloc(c, &kept, c->n_tiles));
+    TRY(dmalloc(c, &base, (uint64_t)c->n_tiles + 1));
+    const uint32_t grid = count_grid(c);
+    RetileParams P{c->tiles, c->tile_len, c->n_tiles, kept, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_retile<false>, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    if (exclusive_scan<uint32_t>(c->stream, kept, c->n_tiles, base, (unsigned long long)c->n_tiles + 1) != 0)
+        return fail(c, YABPE_E_HIP, "retile scan failed: %s", hipGetErrorString(hipGetLastError()));
+    unsigned long long total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, base + c->n_tiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t new_n = std::max<uint32_t>(1, (uint32_t)((total + SPAN - 1) / SPAN));
+    if (!c->tiles_alt || c->tiles_alt_cap < new_n) {
+        dfree(c->tiles_alt);
+        dfree(c->tile_len_alt);
+        c->tiles_alt = nullptr;
+        c->tile_len_alt = nullptr;
+        TRY(dmalloc(c, &c->tiles_alt, (uint64_t)new_n * CAP));
+        TRY(dmalloc(c, &c->tile_len_alt, new_n));
+        c->tiles_alt_cap = new_n;
+    }
+    TRY(fill_u16(c, c->tiles_alt, (uint64_t)new_n * CAP, YB_PAD));
+    HIPCHK(c, hipMemsetAsync(c->tile_len_alt, 0, (size_t)new_n * 4, c->stream));
+    P.base = base;
+    P.new_tiles = c->tiles_alt;
+    P.new_len = c->tile_len_alt;
+    hipLaunchKernelGGL(k_retile<true>, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::swap(c->tiles, c->tiles_alt);
+    std::swap(c->tile_len, c->tile_len_alt);
+    std::swap(c->tiles_cap, c->tiles_alt_cap);
+    c->n_tiles = new_n;
+    dfree(kept);
+    dfree(base);
+    TRY(refresh_live_slots(c));
+    c->stats.retiles++;
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int yabpe_abi_version(void) { return YABPE_ABI_VERSION; }
+
+int yabpe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *yabpe_last_error(const yabpe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int yabpe_create(yabpe_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, YABPE_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, YABPE_E_NODEVICE, "no HIP device available (%s); the BPE hot path has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device_id < 0 || device_id >= n) return fail(nullptr, YABPE_E_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    yabpe_ctx *c = new yabpe_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete c;
+        return fail(nullptr, YABPE_E_HIP, "hipSetDevice(%d) failed", device_id);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&c->st, sizeof(DevState)) != hipSuccess ||
+        hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c->scratch64, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        int code = fail(nullptr, YABPE_E_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        yabpe_destroy(c);
+        return code;
+    }
+    (void)hipMemset(c->st, 0, sizeof(DevState));
+    memset(c->st_host, 0, sizeof(DevState));
+    *out = c;
+    return YABPE_OK;
+}
+
+void yabpe_destroy(yabpe_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    yabpe_synth_free(c);
+    free_corpus(c);
+    free_records(c);
+    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rank); dfree(c->tt.vset);
+    dfree(c->partials);
+    dfree(c->st);
+    dfree(c->scratch64);
+    if (c->st_host) (void)hipHostFree(c->st_host);
+    for (auto &e : c->events) {
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int yabpe_set_option(yabpe_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return YABPE_E_INVALID;
+    c->opt[name] = value;
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- vocab
+int yabpe_set_vocab(yabpe_ctx *c, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tokens) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!tok_bytes || !tok_off || n_tokens < 256) return fail(c, YABPE_E_INVALID, "vocab needs the 256 byte tokens first");
+    for (uint32_t b = 0; b < 256; ++b)
+        if (tok_off[b + 1] - tok_off[b] != 1 || tok_bytes[tok_off[b]] != b)
+            return fail(c, YABPE_E_INVALID, "token %u must be the single byte %u (trainer.py:123-125)", b, b);
+    if (n_tokens >= YB_MAX_TOKENS) return fail(c, YABPE_E_CAPACITY, "base vocabulary too large for u16 token ids");
+    const uint32_t pool_cap = (uint32_t)optv(c, "pool_bytes", 64 << 20);
+    const uint32_t vset_cap = 1u << 18;
+    if (tok_off[n_tokens] > pool_cap / 2) return fail(c, YABPE_E_CAPACITY, "base vocabulary bytes exceed the token pool");
+    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rank); dfree(c->tt.vset);
+    TRY(dmalloc(c, &c->tt.pool, pool_cap));
+    TRY(dmalloc(c, &c->tt.off, YB_MAX_TOKENS));
+    TRY(dmalloc(c, &c->tt.len, YB_MAX_TOKENS));
+    TRY(dmalloc(c, &c->tt.rank, YB_MAX_TOKENS));
+    TRY(dmalloc(c, &c->tt.vset, vset_cap));
+    c->tt.pool_cap = pool_cap;
+    c->tt.vset_mask = vset_cap - 1;
+    std::vector<uint32_t> off(n_tokens), len(n_tokens), rank(n_tokens), order(n_tokens), vset(vset_cap, EMPTY);
+    for (uint32_t i = 0; i < n_tokens; ++i) {
+        off[i] = tok_off[i];
+        len[i] = tok_off[i + 1] - tok_off[i];
+        order[i] = i;
+    }
+    auto cmp = [&](uint32_t x, uint32_t y) {
+        uint32_t n = std::min(len[x], len[y]);
+        int d = memcmp(tok_bytes + off[x], tok_bytes + off[y], n);
+        if (d) return d < 0;
+        return len[x] < len[y];
+    };
+    std::sort(order.begin(), order.end(), cmp);
+    for (uint32_t r = 0; r < n_tokens; ++r) {
+        if (r && !cmp(order[r - 1], order[r])) return fail(c, YABPE_E_INVALID, "duplicate token bytes in the base vocabulary (trainer.py:130)");
+        rank[order[r]] = r;
+    }
+    for (uint32_t i = 0; i < n_tokens; ++i) {
+        uint32_t s = yb_tok_hash(tok_bytes + off[i], len[i]) & c->tt.vset_mask;
+        while (vset[s] != EMPTY) s = (s + 1) & c->tt.vset_mask;
+        vset[s] = i;
+    }
+    HIPCHK(c, hipMemcpy(c->tt.pool, tok_bytes, tok_off[n_tokens], hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.off, off.data(), n_tokens * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.len, len.data(), n_tokens * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.rank, rank.data(), n_tokens * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.vset, vset.data(), (size_t)vset_cap * 4, hipMemcpyHostToDevice));
+    TRY(state_pull(c));
+    DevState *h = c->st_host;
+    memset(h, 0, sizeof(DevState));
+    h->n_tokens = n_tokens;
+    h->pool_used = tok_off[n_tokens];
+    TRY(state_push(c));
+    c->base_tokens = n_tokens;
+    c->have_vocab = true;
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- corpus
+int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_off, const uint64_t *word_freq,
+                     uint64_t n_words, uint32_t flags) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_vocab) return fail(c, YABPE_E_INVALID, "call yabpe_set_vocab first");
+    if (!word_off) return fail(c, YABPE_E_INVALID, "word_off is NULL");
+    if (n_words >= 0xFFFFFFFFull) return fail(c, YABPE_E_CAPACITY, "more than 2^32-2 words per context");
+    free_corpus(c);
+    hipEvent_t ev0, ev1;
+    HIPCHK(c, hipEventCreate(&ev0));
+    HIPCHK(c, hipEventCreate(&ev1));
+
+    // ---- make inputs device-resident
+    const unsigned long long *d_off = nullptr;
+    const uint8_t *d_bytes = nullptr;
+    const unsigned long long *d_freq = nullptr;
+    void *own_off = nullptr, *own_bytes = nullptr, *own_freq = nullptr;
+    uint64_t total_bytes = 0;
+    if (is_device_ptr(word_off)) {
+        d_off = (const unsigned long long *)word_off;
+        HIPCHK(c, hipMemcpy(&total_bytes, word_off + n_words, 8, hipMemcpyDeviceToHost));
+    } else {
+        total_bytes = word_off[n_words];
+        HIPCHK(c, hipMalloc(&own_off, (n_words + 1) * 8));
+        HIPCHK(c, hipMemcpy(own_off, word_off, (n_words + 1) * 8, hipMemcpyHostToDevice));
+        d_off = (const unsigned long long *)own_off;
+    }
+    if (total_bytes && !bytes) return fail(c, YABPE_E_INVALID, "bytes is NULL");
+    if (is_device_ptr(bytes) || total_bytes == 0) {
+        d_bytes = bytes;
+    } else {
+        HIPCHK(c, hipMalloc(&own_bytes, total_bytes));
+        HIPCHK(c, hipMemcpy(own_bytes, bytes, total_bytes, hipMemcpyHostToDevice));
+        d_bytes = (const uint8_t *)own_bytes;
+    }
+    if (word_freq) {
+        if (is_device_ptr(word_freq)) {
+            d_freq = (const unsigned long long *)word_freq;
+        } else {
+            HIPCHK(c, hipMalloc(&own_freq, std::max<uint64_t>(n_words, 1) * 8));
+            HIPCHK(c, hipMemcpy(own_freq, word_freq, n_words * 8, hipMemcpyHostToDevice));
+            d_freq = (const unsigned long long *)own_freq;
+        }
+    }
+    auto cleanup_inputs = [&]() { dfree(own_off); dfree(own_bytes); dfree(own_freq); own_off = own_bytes = own_freq = nullptr; };
+    HIPCHK(c, hipEventRecord(ev0, c->stream));
+
+    c->n_words_input = n_words;
+    // ---- optional device-side pooling of equal words (trainer.py:221-225)
+    DedupOut dd{};
+    if ((flags & YABPE_LOAD_DEDUP) && n_words > 0) {
+        int r = dedup_words(c->stream, d_bytes, d_off, d_freq, n_words, total_bytes, &dd);
+        if (r != 0) { cleanup_inputs(); return fail(c, YABPE_E_HIP, "device dedup failed (%d): %s", r, hipGetErrorString(hipGetLastError())); }
+        cleanup_inputs();
+        own_bytes = dd.bytes; own_off = dd.off; own_freq = dd.freq;
+        d_bytes = dd.bytes; d_off = dd.off; d_freq = dd.freq;
+        n_words = dd.n_unique;
+        total_bytes = dd.total_bytes;
+    }
+    c->weighted = d_freq != nullptr;
+    c->n_words = n_words;
+    c->tokens_initial = total_bytes;
+
+    // ---- tiles
+    const uint64_t packed = total_bytes + n_words;
+    const uint64_t n_tiles64 = (packed + SPAN - 1) / SPAN;
+    if (n_tiles64 >= 0xFFFFFFF0ull) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "corpus too large for one context"); }
+    c->n_tiles = (uint32_t)n_tiles64;
+    c->tiles_cap = c->n_tiles;
+    c->tiles_alt_cap = 0;
+    TRY(dmalloc(c, &c->tiles, (uint64_t)c->n_tiles * CAP));
+    TRY(dmalloc(c, &c->tile_len, c->n_tiles));
+    if (c->weighted) {
+        TRY(dmalloc(c, &c->tile_wbase, c->n_tiles));
+        TRY(dmalloc(c, &c->wfreq, n_words));
+        HIPCHK(c, hipMemsetAsync(&c->scratch64[1], 0, 8, c->stream));
+        if (n_words) {
+            hipLaunchKernelGGL(k_freq64_to_32, dim3(cdiv64(n_words, 256)), dim3(256), 0, c->stream, d_freq, c->wfreq,
+                               (unsigned long long)n_words, (uint32_t *)&c->scratch64[1]);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    uint32_t long_cap = (uint32_t)optv(c, "long_cap", 1 << 16);
+    uint32_t *d_long_word = nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        TRY(fill_u16(c, c->tiles, (uint64_t)c->n_tiles * CAP, YB_PAD));
+        HIPCHK(c, hipMemsetAsync(c->tile_len, 0, (size_t)c->n_tiles * 4, c->stream));
+        if (c->weighted) TRY(fill_u32(c, c->tile_wbase, c->n_tiles, 0xFFFFFFFFu));
+        HIPCHK(c, hipMemsetAsync(&c->scratch64[2], 0, 16, c->stream));  // [2] = long count (u32), [3] = long tokens
+        dfree(d_long_word);
+        TRY(dmalloc(c, &d_long_word, long_cap));
+        if (n_words) {
+            LoadParams P{d_bytes, d_off, (unsigned long long)n_words, c->tiles, c->tile_len, c->tile_wbase,
+                         (uint32_t *)&c->scratch64[2], &c->scratch64[3], d_long_word, long_cap};
+            hipLaunchKernelGGL(k_load_words, dim3(cdiv64(n_words, BLOCK)), dim3(BLOCK), 0, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        unsigned long long host2[2];
+        HIPCHK(c, hipMemcpyAsync(host2, &c->scratch64[2], 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n_long = (uint32_t)(host2[0] & 0xFFFFFFFFu);
+        c->long_tokens = host2[1];
+        if (c->n_long <= long_cap) break;
+        long_cap = c->n_long;
+        if (attempt == 1) { cleanup_inputs(); return fail(c, YABPE_E_INTERNAL, "long-word list overflow"); }
+    }
+    if (c->weighted) {
+        unsigned long long ov = 0;
+        HIPCHK(c, hipMemcpy(&ov, &c->scratch64[1], 8, hipMemcpyDeviceToHost));
+        if (ov & 0xFFFFFFFFu) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "a word frequency exceeds 2^32-1"); }
+    }
+    // ---- long words: own buffer, one workgroup per word
+    if (c->n_long) {
+        std::vector<uint32_t> lw(c->n_long);
+        HIPCHK(c, hipMemcpy(lw.data(), d_long_word, (size_t)c->n_long * 4, hipMemcpyDeviceToHost));
+        std::sort(lw.begin(), lw.end());  // deterministic layout
+        HIPCHK(c, hipMemcpy(d_long_word, lw.data(), (size_t)c->n_long * 4, hipMemcpyHostToDevice));
+        std::vector<unsigned long long> loff(c->n_long + 1, 0);
+        for (uint32_t i = 0; i < c->n_long; ++i) {
+            unsigned long long o[2];
+            HIPCHK(c, hipMemcpy(o, d_off + lw[i], 16, hipMemcpyDeviceToHost));
+            loff[i + 1] = loff[i] + (o[1] - o[0]);
+            if (o[1] - o[0] > 0xFFFFFFFFull) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "a single word longer than 2^32-1 bytes"); }
+        }
+        TRY(dmalloc(c, &c->long_tok, loff[c->n_long]));
+        TRY(dmalloc(c, &c->long_off, c->n_long + 1));
+        TRY(dmalloc(c, &c->long_len, c->n_long));
+        if (c->weighted) TRY(dmalloc(c, &c->long_freq, c->n_long));
+        HIPCHK(c, hipMemcpy(c->long_off, loff.data(), (size_t)(c->n_long + 1) * 8, hipMemcpyHostToDevice));
+        LoadLongParams L{d_bytes, d_off, d_freq, d_long_word, c->long_off, c->long_tok, c->long_len, c->long_freq, c->n_long};
+        hipLaunchKernelGGL(k_load_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(d_long_word);
+    cleanup_inputs();
+
+    // ---- state + initial pair count (trainer.py:227-235)
+    TRY(state_pull(c));
+    DevState *h = c->st_host;
+    h->iter = 0; h->done = 0; h->halt = 0; h->halt_req = 0; h->sites = 0;
+    h->tokens_now = total_bytes;
+    h->table_entries = 0;
+    TRY(state_push(c));
+    TRY(refresh_live_slots(c));
+    TRY(table_rebuild(c, 0));
+    c->stats.table_rebuilds = 0;
+    HIPCHK(c, hipEventRecord(ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    c->stats.load_ms = ms;
+    c->stats.retiles = 0;
+    c->stats.train_ms = 0;
+    c->stats.apply_ms_sampled = 0;
+    c->stats.apply_launches_sampled = 0;
+    c->stats.apply_algo_bytes_sampled = 0;
+    c->stats.apply_actual_bytes_sampled = 0;
+    c->stats.algo_bytes_total = 0;
+    c->have_words = true;
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- train
+static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev) {
+    ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
+    hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
+    SelectParams S{c->partials, c->n_partials, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
+                   c->rec_count, c->rec_sites, c->rec_live, rec_base};
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
+    RankParams R{c->tt, c->st};
+    hipLaunchKernelGGL(k_rank_update, dim3(cdiv64(tokens_upper, BLOCK)), dim3(BLOCK), 0, c->stream, R);
+    if (ev) HIPCHK(c, hipEventRecord(ev->e0, c->stream));
+    if (c->n_tiles) {
+        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->table, c->st};
+        if (c->weighted)
+            hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+        else
+            hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+    }
+    if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+    if (c->n_long) {
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, c->table, c->st};
+        hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint32_t *out_left, uint32_t *out_right,
+                uint32_t *out_merged, uint64_t *out_count, uint32_t *out_n_merges) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_words) return fail(c, YABPE_E_INVALID, "call yabpe_load_words first");
+    if (out_n_merges) *out_n_merges = 0;
+    TRY(state_pull(c));
+    DevState *h = c->st_host;
+    if ((uint64_t)h->n_tokens + num_merges > YB_MAX_TOKENS)
+        return fail(c, YABPE_E_CAPACITY, "vocabulary of %llu tokens exceeds the u16 id space (max %u)",
+                    (unsigned long long)h->n_tokens + num_merges, (unsigned)YB_MAX_TOKENS);
+    const uint32_t rec_base = h->iter;
+    h->num_merges = rec_base + num_merges;
+    h->min_freq = min_frequency;
+    h->done = 0;
+    h->halt = 0;
+    h->halt_req = 0;
+    TRY(state_push(c));
+    c->rec_n = 0;
+    c->log_sites.clear();
+    c->log_live.clear();
+    if (num_merges == 0) return YABPE_OK;
+
+    if (c->rec_cap < num_merges) {
+        free_records(c);
+        TRY(dmalloc(c, &c->rec_left, num_merges));
+        TRY(dmalloc(c, &c->rec_right, num_merges));
+        TRY(dmalloc(c, &c->rec_merged, num_merges));
+        TRY(dmalloc(c, &c->rec_count, num_merges));
+        TRY(dmalloc(c, &c->rec_sites, num_merges));
+        TRY(dmalloc(c, &c->rec_live, num_merges));
+        c->rec_cap = num_merges;
+    }
+    HIPCHK(c, hipMemsetAsync(c->rec_sites, 0, (size_t)num_merges * 8, c->stream));
+
+    const uint32_t check = (uint32_t)std::max<int64_t>(1, optv(c, "check_interval", 64));
+    const uint32_t ev_sample = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample", 0));
+    const double retile_frac = (double)optv(c, "retile_pct", 60) / 100.0;
+    const uint64_t retile_min_tiles = (uint64_t)optv(c, "retile_min_tiles", 4096);
+    std::vector<EventPair> used_events;
+    size_t ev_next = 0;
+
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+
+    uint32_t tokens_start = h->n_tokens;
+    uint32_t i = 0;
+    bool finished = false;
+    while (!finished) {
+        // (re)size the argmax grid to the table
+        uint32_t want_partials = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
+        if (want_partials != c->n_partials) {
+            dfree(c->partials);
+            c->partials = nullptr;
+            TRY(dmalloc(c, &c->partials, want_partials));
+            c->n_partials = want_partials;
+        }
+        const uint32_t apply_grid = count_grid(c);
+        uint32_t batch_end = std::min(num_merges, i + check);
+        for (; i < batch_end; ++i) {
+            EventPair *ev = nullptr;
+            if (ev_sample && (i % ev_sample) == 0) {
+                if (ev_next == c->events.size()) {
+                    EventPair n{};
+                    HIPCHK(c, hipEventCreate(&n.e0));
+                    HIPCHK(c, hipEventCreate(&n.e1));
+                    c->events.push_back(n);
+                }
+                c->events[ev_next].iter_rel = i;
+                ev = &c->events[ev_next++];
+            }
+            TRY(launch_iteration(c, rec_base, tokens_start + i + 1, apply_grid, ev));
+        }
+        TRY(state_pull(c));
+        if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
+        if (h->halt) {
+            if (h->halt == HALT_TABLE_FULL) {
+                // the stream is consistent (the apply pass finished); only the table lost updates: rebuild it bigger
+                h->halt = 0; h->halt_req = 0;
+                TRY(state_push(c));
+                TRY(table_rebuild(c, c->table_cap * 4));
+                TRY(state_pull(c));
+                i = h->iter - rec_base;  // resume after the last recorded merge
+                continue;
+            }
+            const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
+                              : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
+                                                           : "device halt";
+            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+            return fail(c, YABPE_E_CAPACITY, "%s after %u merges", why, h->iter - rec_base);
+        }
+        if (h->done || i >= num_merges) {
+            finished = true;
+            break;
+        }
+        // housekeeping between batches
+        if (h->table_entries * 4 > c->table_cap) TRY(table_rebuild(c, c->table_cap * 2));
+        if (c->n_tiles >= retile_min_tiles && !c->weighted &&
+            (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
+            TRY(retile_flat(c));
+        }
+    }
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(t1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    c->stats.train_ms += ms;
+
+    // close the log of the last iteration and fold the remaining sites into T_i
+    TRY(state_pull(c));
+    const uint32_t n = h->iter - rec_base;
+    c->rec_n = n;
+    c->log_sites.assign(n, 0);
+    c->log_live.assign(n, 0);
+    if (n) {
+        HIPCHK(c, hipMemcpy(c->log_sites.data(), c->rec_sites, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->log_live.data(), c->rec_live, (size_t)n * 8, hipMemcpyDeviceToHost));
+        c->log_sites[n - 1] = h->sites;
+    }
+    const uint64_t tokens_at_start = h->tokens_now + [&] { uint64_t s = 0; for (uint32_t k = 0; k + 1 < n; ++k) s += c->log_sites[k]; return s; }();
+    h->tokens_now -= h->sites;
+    h->sites = 0;
+    TRY(state_push(c));
+    // algorithmic bytes: A_i = 2 * (T_i + W)
+    {
+        uint64_t T = tokens_at_start;
+        std::vector<uint64_t> Ti(n);
+        for (uint32_t k = 0; k < n; ++k) {
+            Ti[k] = T;
+            c->stats.algo_bytes_total += 2 * (T + c->n_words_input);
+            T -= c->log_sites[k];
+        }
+        for (size_t e = 0; e < ev_next; ++e) {
+            uint32_t k = c->events[e].iter_rel;
+            if (k >= n) continue;
+            float ems = 0;
+            if (hipEventElapsedTime(&ems, c->events[e].e0, c->events[e].e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            c->stats.apply_ms_sampled += ems;
+            c->stats.apply_launches_sampled += 1;
+            c->stats.apply_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
+            c->stats.apply_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
+        }
+    }
+    if (n) {
+        if (out_left) HIPCHK(c, hipMemcpy(out_left, c->rec_left, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (out_right) HIPCHK(c, hipMemcpy(out_right, c->rec_right, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (out_merged) HIPCHK(c, hipMemcpy(out_merged, c->rec_merged, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (out_count) HIPCHK(c, hipMemcpy(out_count, c->rec_count, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    if (out_n_merges) *out_n_merges = n;
+    if (optv(c, "verify", 0)) {
+        uint64_t mm = 0;
+        TRY(yabpe_verify_table(c, &mm));
+        if (mm) return fail(c, YABPE_E_INTERNAL, "incremental pair table differs from a recount in %llu keys", (unsigned long long)mm);
+    }
+    return YABPE_OK;
+}
+
+int yabpe_n_tokens(yabpe_ctx *c, uint32_t *out) {
+    if (!c || !out) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(state_pull(c));
+    *out = c->st_host->n_tokens;
+    return YABPE_OK;
+}
+
+int yabpe_token_bytes(yabpe_ctx *c, uint32_t id, uint8_t *out, uint32_t cap, uint32_t *out_len) {
+    if (!c || !out_len) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(state_pull(c));
+    if (id >= c->st_host->n_tokens) return fail(c, YABPE_E_INVALID, "token id %u out of range", id);
+    uint32_t off = 0, len = 0;
+    HIPCHK(c, hipMemcpy(&off, c->tt.off + id, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&len, c->tt.len + id, 4, hipMemcpyDeviceToHost));
+    *out_len = len;
+    if (out && cap >= len && len) HIPCHK(c, hipMemcpy(out, c->tt.pool + off, len, hipMemcpyDeviceToHost));
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stats / debug
+int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
+    if (!c || !out) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(state_pull(c));
+    c->stats.n_words = c->n_words;
+    c->stats.n_words_input = c->n_words_input;
+    c->stats.n_long_words = c->n_long;
+    c->stats.tokens_initial = c->tokens_initial;
+    c->stats.tokens_now = c->st_host->tokens_now;
+    c->stats.merges_done = c->st_host->iter;
+    c->stats.n_tiles = c->n_tiles;
+    c->stats.live_slots = c->st_host->live_slots;
+    c->stats.table_capacity = c->table_cap;
+    c->stats.table_entries = c->st_host->table_entries;
+    *out = c->stats;
+    return YABPE_OK;
+}
+
+int yabpe_iter_log(yabpe_ctx *c, uint64_t *out_sites, uint64_t *out_live_slots, uint32_t cap, uint32_t *out_n) {
+    if (!c || !out_n) return YABPE_E_INVALID;
+    uint32_t n = std::min<uint32_t>(cap, (uint32_t)c->log_sites.size());
+    if (out_sites) memcpy(out_sites, c->log_sites.data(), (size_t)n * 8);
+    if (out_live_slots) memcpy(out_live_slots, c->log_live.data(), (size_t)n * 8);
+    *out_n = (uint32_t)c->log_sites.size();
+    return YABPE_OK;
+}
+
+int yabpe_verify_table(yabpe_ctx *c, uint64_t *out_mismatches) {
+    if (!c || !out_mismatches) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_words) return fail(c, YABPE_E_INVALID, "no corpus loaded");
+    PairTable scratch{};
+    HIPCHK(c, hipMemsetAsync(&c->scratch64[4], 0, 16, c->stream));  // [4] entries, [5] mismatches
+    TRY(table_alloc(c, scratch, c->table_cap, &c->scratch64[4]));
+    TRY(launch_count(c, scratch));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / BLOCK));
+    CmpParams A{c->table, scratch, &c->scratch64[5]};
+    hipLaunchKernelGGL(k_table_compare, dim3(grid), dim3(BLOCK), 0, c->stream, A);
+    CmpParams B{scratch, c->table, &c->scratch64[5]};
+    hipLaunchKernelGGL(k_table_compare, dim3(grid), dim3(BLOCK), 0, c->stream, B);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long mm = 0;
+    HIPCHK(c, hipMemcpyAsync(&mm, &c->scratch64[5], 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    table_free(scratch);
+    // the recount may have raised halt_req on the scratch table; it is not a training halt
+    HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, 4, c->stream));
+    *out_mismatches = mm;
+    return YABPE_OK;
+}
+
+int yabpe_stream_checksum(yabpe_ctx *c, uint64_t *out_sum, uint64_t *out_words, uint64_t *out_tokens) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_words) return fail(c, YABPE_E_INVALID, "no corpus loaded");
+    HIPCHK(c, hipMemsetAsync(&c->scratch64[4], 0, 24, c->stream));
+    if (c->n_tiles) {
+        ChecksumParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->tt,
+                         &c->scratch64[4], &c->scratch64[5], &c->scratch64[6]};
+        hipLaunchKernelGGL(k_stream_checksum, dim3(cdiv64(c->n_tiles, BLOCK)), dim3(BLOCK), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    unsigned long long r[3];
+    HIPCHK(c, hipMemcpyAsync(r, &c->scratch64[4], 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_sum) *out_sum = r[0];
+    if (out_words) *out_words = r[1];
+    if (out_tokens) *out_tokens = r[2];
+    return YABPE_OK;
+}
+
+int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t n) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst_host, src_dev, n, hipMemcpyDeviceToHost));
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- synthetic corpus
+int yabpe_synth_generate(yabpe_ctx *c, uint64_t target_bytes, uint32_t n_types, uint64_t seed, const uint8_t *alphabet,
+                         uint32_t alphabet_len, int space_prefix, uint8_t **out_dev_bytes, uint64_t **out_dev_off,
+                         uint64_t *out_n_words, uint64_t *out_n_bytes) {
+    if (!c || !alphabet || !alphabet_len || !n_types || !out_dev_bytes || !out_dev_off || !out_n_words || !out_n_bytes)
+        return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    SynthOut so{};
+    int r = synth_generate(c->stream, target_bytes, n_types, seed, alphabet, alphabet_len, space_prefix, &so);
+    if (r != 0) return fail(c, r == -2 ? YABPE_E_INTERNAL : YABPE_E_HIP, "synthetic generation failed (%d): %s", r, hipGetErrorString(hipGetLastError()));
+    c->synth_bufs.push_back(so.bytes);
+    c->synth_bufs.push_back(so.off);
+    *out_dev_bytes = so.bytes;
+    *out_dev_off = (uint64_t *)so.off;
+    *out_n_words = so.n_words;
+    *out_n_bytes = so.n_bytes;
+    return YABPE_OK;
+}
+
+int yabpe_synth_free(yabpe_ctx *c) {
+    if (!c) return YABPE_E_INVALID;
+    for (void *p : c->synth_bufs) dfree(p);
+    c->synth_bufs.clear();
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- multi-GPU (see yabpe_comm.h)
+int yabpe_comm_unique_id(uint8_t out_id[128]) {
+    (void)out_id;
+    return YABPE_E_COMM;
+}
+int yabpe_comm_init(yabpe_ctx *c, int rank, int n_ranks, const uint8_t unique_id[128]) {
+    (void)rank; (void)n_ranks; (void)unique_id;
+    return fail(c, YABPE_E_COMM, "multi-GPU exchange not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+"""ctypes binding of libyabpe.so (C ABI: include/yabpe.h) -- the only way the Python host reaches the GPU.
+
+No fallback of any kind: if the library is not built, or no MI355X is visible, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+from pathlib import Path
+
+import numpy as np
+
+_CSRC = Path(__file__).resolve().parent.parent / "csrc"
+LIB_PATH = Path(os.environ.get("YABPE_LIB", _CSRC / "libyabpe.so"))
+
+
+class YabpeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"yabpe error {code}: {msg}")
+        self.code = code
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, c_uint64) for n in (
+        "n_words", "n_words_input", "n_long_words", "tokens_initial", "tokens_now", "merges_done", "n_tiles",
+        "live_slots", "table_capacity", "table_entries", "retiles", "table_rebuilds")] + [
+        ("load_ms", c_double), ("train_ms", c_double), ("apply_ms_sampled", c_double)] + [(n, c_uint64) for n in (
+            "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")]
+
+
+_lib = None
+
+# every symbol include/yabpe.h declares (tests/test_abi.py checks the library exports all of them)
+SYMBOLS = [
+    "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
+    "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
+    "yabpe_iter_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
+    "yabpe_memcpy_d2h", "yabpe_comm_unique_id", "yabpe_comm_init",
+]
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C {_CSRC}` (hipcc --offload-arch=gfx950). "
+                "The BPE hot path has no CPU fallback.")
+        L = ctypes.CDLL(str(LIB_PATH))
+        L.yabpe_abi_version.restype = c_int
+        L.yabpe_device_count.restype = c_int
+        L.yabpe_create.argtypes = [POINTER(c_void_p), c_int]
+        L.yabpe_destroy.argtypes = [c_void_p]
+        L.yabpe_destroy.restype = None
+        L.yabpe_last_error.argtypes = [c_void_p]
+        L.yabpe_last_error.restype = c_char_p
+        L.yabpe_set_option.argtypes = [c_void_p, c_char_p, c_int64]
+        L.yabpe_set_vocab.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32]
+        L.yabpe_load_words.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32]
+        L.yabpe_train.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_uint32)]
+        L.yabpe_n_tokens.argtypes = [c_void_p, POINTER(c_uint32)]
+        L.yabpe_token_bytes.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_uint32)]
+        L.yabpe_stats.argtypes = [c_void_p, POINTER(Stats)]
+        L.yabpe_iter_log.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
+        L.yabpe_verify_table.argtypes = [c_void_p, POINTER(c_uint64)]
+        L.yabpe_stream_checksum.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
+        L.yabpe_synth_generate.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32, c_int,
+                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]
+        L.yabpe_synth_free.argtypes = [c_void_p]
+        L.yabpe_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
+        L.yabpe_comm_unique_id.argtypes = [c_void_p]
+        L.yabpe_comm_init.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        if L.yabpe_abi_version() != 1:
+            raise ImportError("libyabpe.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+LOAD_DEDUP = 0x1
+
+
+class Context:
+    """One GPU context == one merge-loop run (or several yabpe_train continuations)."""
+
+    def __init__(self, device: int | None = None):
+        L = lib()
+        if device is None:
+            device = int(os.environ.get("YABPE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self._h = c_void_p()
+        rc = L.yabpe_create(byref(self._h), device)
+        if rc != 0:
+            raise YabpeError(rc, L.yabpe_last_error(None).decode())
+        self.device = device
+        for k, v in os.environ.items():  # YABPE_OPT_check_interval=16 etc.
+            if k.startswith("YABPE_OPT_"):
+                self.set_option(k[len("YABPE_OPT_"):], int(v))
+
+    # -- lifetime
+    def close(self) -> None:
+        if self._h:
+            lib().yabpe_destroy(self._h)
+            self._h = c_void_p()
+
+    def __enter__(self) -> "Context":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise YabpeError(rc, lib().yabpe_last_error(self._h).decode())
+
+    # -- API
+    def set_option(self, name: str, value: int) -> None:
+        self._chk(lib().yabpe_set_option(self._h, name.encode(), int(value)))
+
+    def set_vocab(self, tokens: list[bytes]) -> None:
+        blob = np.frombuffer(b"".join(tokens), dtype=np.uint8)
+        off = np.zeros(len(tokens) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(t) for t in tokens])
+        self._base = list(tokens)
+        self._chk(lib().yabpe_set_vocab(self._h, blob.ctypes.data, off.ctypes.data, len(tokens)))
+
+    def load_words(self, flat, off, freq=None, dedup: bool = False) -> None:
+        """flat: u8 bytes, off: u64 offsets (n+1), freq: optional u64 counts.  numpy arrays (host) or
+        integer device addresses wrapped as (ptr, n) via load_words_ptr."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        fq = None
+        if freq is not None:
+            fq = np.ascontiguousarray(freq, dtype=np.uint64)
+            assert len(fq) == n
+        self._keep = (flat, off, fq)
+        self._chk(lib().yabpe_load_words(self._h, flat.ctypes.data if flat.size else None, off.ctypes.data,
+                                         fq.ctypes.data if fq is not None else None, n, LOAD_DEDUP if dedup else 0))
+
+    def load_words_ptr(self, bytes_ptr: int, off_ptr: int, n_words: int, freq_ptr: int = 0, dedup: bool = False) -> None:
+        """Device (or host) addresses, e.g. from synth_generate() or torch tensors' data_ptr()."""
+        self._chk(lib().yabpe_load_words(self._h, c_void_p(bytes_ptr), c_void_p(off_ptr),
+                                         c_void_p(freq_ptr) if freq_ptr else None, n_words, LOAD_DEDUP if dedup else 0))
+
+    def train(self, num_merges: int, min_frequency: int):
+        left = np.zeros(max(num_merges, 1), dtype=np.uint32)
+        right = np.zeros_like(left)
+        merged = np.zeros_like(left)
+        count = np.zeros(max(num_merges, 1), dtype=np.uint64)
+        n = c_uint32(0)
+        self._chk(lib().yabpe_train(self._h, num_merges, min_frequency, left.ctypes.data, right.ctypes.data,
+                                    merged.ctypes.data, count.ctypes.data, byref(n)))
+        k = n.value
+        return left[:k], right[:k], merged[:k], count[:k]
+
+    def n_tokens(self) -> int:
+        n = c_uint32(0)
+        self._chk(lib().yabpe_n_tokens(self._h, byref(n)))
+        return n.value
+
+    def token_bytes(self, tid: int) -> bytes:
+        ln = c_uint32(0)
+        self._chk(lib().yabpe_token_bytes(self._h, tid, None, 0, byref(ln)))
+        buf = (c_uint8 * max(ln.value, 1))()
+        self._chk(lib().yabpe_token_bytes(self._h, tid, buf, ln.value, byref(ln)))
+        return bytes(buf[:ln.value])
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(lib().yabpe_stats(self._h, byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def iter_log(self):
+        n = c_uint32(0)
+        self._chk(lib().yabpe_iter_log(self._h, None, None, 0, byref(n)))
+        sites = np.zeros(max(n.value, 1), dtype=np.uint64)
+        live = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self._chk(lib().yabpe_iter_log(self._h, sites.ctypes.data, live.ctypes.data, n.value, byref(n)))
+        return sites[:n.value], live[:n.value]
+
+    def verify_table(self) -> int:
+        m = c_uint64(0)
+        self._chk(lib().yabpe_verify_table(self._h, byref(m)))
+        return m.value
+
+    def stream_checksum(self) -> tuple[int, int, int]:
+        a, b, c = c_uint64(0), c_uint64(0), c_uint64(0)
+        self._chk(lib().yabpe_stream_checksum(self._h, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
+    def synth_generate(self, target_bytes: int, n_types: int, seed: int, alphabet: bytes, space_prefix: bool):
+        """-> (dev_bytes_ptr, dev_off_ptr, n_words, n_bytes); buffers live until close()/synth_free()."""
+        al = np.frombuffer(alphabet, dtype=np.uint8)
+        pb, po, nw, nb = c_void_p(), c_void_p(), c_uint64(0), c_uint64(0)
+        self._chk(lib().yabpe_synth_generate(self._h, target_bytes, n_types, seed, al.ctypes.data, len(al),
+                                             1 if space_prefix else 0, byref(pb), byref(po), byref(nw), byref(nb)))
+        return pb.value, po.value, nw.value, nb.value
+
+    def synth_free(self) -> None:
+        self._chk(lib().yabpe_synth_free(self._h))
+
+    def d2h(self, dev_ptr: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(lib().yabpe_memcpy_d2h(self._h, out.ctypes.data, c_void_p(dev_ptr), nbytes))
+        return out
+
+
+def train_words(words_flat, words_off, freq, base_tokens: list[bytes], num_merges: int, min_frequency: int,
+                dedup: bool = False, options: dict | None = None, want_stats: bool = False):
+    """Convenience used by tests/bench: returns (vocab, merges[, stats]) like _merge_loop."""
+    with Context() as ctx:
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_vocab(base_tokens)
+        ctx.load_words(words_flat, words_off, freq, dedup=dedup)
+        left, right, merged, count = ctx.train(num_merges, min_frequency)
+        stats = ctx.stats() if want_stats else None
+    toks = list(base_tokens)
+    merges = []
+    for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+        merges.append((toks[l], toks[r]))
+        if m == len(toks):
+            toks.append(toks[l] + toks[r])
+        else:
+            assert toks[m] == toks[l] + toks[r], "merged id does not name left+right"
+    vocab = {t: i for i, t in enumerate(toks)}
+    return (vocab, merges, stats) if want_stats else (vocab, merges)
