@@ -29,6 +29,7 @@ struct Model {
     std::unordered_map<std::string, uint32_t> vocab;
     std::vector<uint32_t> m_left, m_right, m_merged;
     std::vector<uint64_t> m_count;
+    bool keep_mismatch = false;
 };
 
 void add_delta(Model &m, uint32_t key, int64_t d) { m.table[key] += d; }
@@ -49,7 +50,7 @@ void count_all(Model &m) {
             add_delta(m, yb_pairkey(m.longw[i][p], m.longw[i][p + 1]), (int64_t)m.longf[i]);
 }
 
-void apply_tile(Model &m, size_t t, uint32_t a, uint32_t b, uint32_t c) {
+void apply_tile(Model &m, size_t t, uint32_t a, uint32_t b, uint32_t c, bool verify_keep = true) {
     auto &v = m.tiles[t];
     int n = (int)v.size();
     auto T = [&](int q) -> uint32_t { return (q < 0 || q >= n) ? YB_PAD : v[q]; };
@@ -77,14 +78,30 @@ void apply_tile(Model &m, size_t t, uint32_t a, uint32_t b, uint32_t c) {
         int64_t w = m.weighted ? (int64_t)m.freq[wi] : 1;
         YbDeltas d;
         yb_site_deltas(p, a, b, c, T, M, d);
-        for (int i = 0; i < d.n; i++) add_delta(m, d.key[i], d.sign[i] * w);
+        if (d.left) { add_delta(m, d.lo, -w); add_delta(m, d.ln, +w); }
+        if (d.right) { add_delta(m, d.ro, -w); add_delta(m, d.rn, +w); }
         add_delta(m, yb_pairkey(a, b), -w);
     }
-    // compaction
+    // compaction, site-driven (what k_apply does): drop b of every site, PAD, and dead (a b) words in flat mode
+    std::vector<uint8_t> drop(n + 4, 0);
+    for (int p = 0; p < n; p++) {
+        if (v[p] == YB_PAD) drop[p] = 1;
+        if (!mr[p]) continue;
+        drop[p + 1] = 1;
+        if (!m.weighted && yb_site_word_dies(p, T)) { drop[p] = 1; drop[p + 2] = 1; }
+    }
     std::vector<uint16_t> out;
     for (int p = 0; p < n; p++) {
-        uint32_t o;
-        if (yb_keep(p, c, !m.weighted, T, M, o)) out.push_back((uint16_t)o);
+        if (drop[p]) continue;
+        out.push_back(mr[p] ? (uint16_t)c : v[p]);
+    }
+    if (verify_keep) {  // the position-wise rule (used by retile) must agree
+        std::vector<uint16_t> out2;
+        for (int p = 0; p < n; p++) {
+            uint32_t o;
+            if (yb_keep(p, c, !m.weighted, T, M, o)) out2.push_back((uint16_t)o);
+        }
+        if (out2 != out) m.keep_mismatch = true;
     }
     v.swap(out);
 }
@@ -156,13 +173,16 @@ int tile_model_train(const uint8_t *bytes, const uint64_t *off, const uint64_t *
         size_t k = (size_t)(P / m.S);
         int slot = (int)(P - (uint64_t)k * m.S);
         if (m.weighted) { m.freq.push_back(wfreq[w]); m.wbase[k] = std::min(m.wbase[k], (uint32_t)w); }
+        if (!m.weighted && L <= 1) continue;  // can never form a pair (trainer.py:231)
         if (L + 1 > (uint64_t)m.LMAX) {
             std::vector<uint16_t> lw(L);
             for (uint64_t j = 0; j < L; j++) lw[j] = bytes[off[w] + j];
             m.longw.push_back(lw);
             m.longf.push_back(m.weighted ? wfreq[w] : 1);
-            slots[k][slot] = YB_SEP;
-            tlen[k] = std::max<uint32_t>(tlen[k], slot + 1);
+            if (m.weighted) {
+                slots[k][slot] = YB_SEP;  // placeholder keeps word indices aligned
+                tlen[k] = std::max<uint32_t>(tlen[k], slot + 1);
+            }
             continue;
         }
         for (uint64_t j = 0; j < L; j++) slots[k][slot + j] = bytes[off[w] + j];
@@ -199,6 +219,7 @@ int tile_model_train(const uint8_t *bytes, const uint64_t *off, const uint64_t *
         for (size_t i = 0; i < m.longw.size(); i++) apply_long(m, i, a, b, c);
         out_left[done] = a; out_right[done] = b; out_merged[done] = c; out_count[done] = (uint64_t)bc;
         done++;
+        if (m.keep_mismatch) return -2000000 - (int)it;
         if (verify) {
             auto inc = m.table;
             count_all(m);

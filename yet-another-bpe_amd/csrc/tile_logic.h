@@ -29,31 +29,29 @@ YB_HD uint32_t yb_pairkey(uint32_t left, uint32_t right) { return (left << 16) |
 YB_HD uint32_t yb_memkey(uint32_t left, uint32_t right) { return (right << 16) | left; }
 
 struct YbDeltas {
-    uint32_t key[4];
-    int32_t sign[4];
-    int n;
+    // fixed slots (no runtime-indexed arrays, so the device keeps them in registers):
+    //   left:  lo -1, ln +1     right: ro -1, rn +1
+    uint32_t lo, ln, ro, rn;
+    bool left, right;
 };
 
 // Neighbour deltas of merge site p (the site's own (a,b) -1 is accounted separately).
 //   T(q): token at position q of the tile (PAD outside), M(q): 1 if q is a merge site (0 outside).
 template <class TokF, class MrgF>
 YB_HD void yb_site_deltas(int p, uint32_t a, uint32_t b, uint32_t c, TokF T, MrgF M, YbDeltas &d) {
-    d.n = 0;
-    uint32_t L = T(p - 1);
-    if (L < YB_PAD) {
-        if (M(p - 2)) { // left neighbour is the b of the site at p-2: old pair (b,a), new pair (c,c)
-            d.key[d.n] = yb_pairkey(b, a); d.sign[d.n++] = -1;
-            d.key[d.n] = yb_pairkey(c, c); d.sign[d.n++] = +1;
-        } else {
-            d.key[d.n] = yb_pairkey(L, a); d.sign[d.n++] = -1;
-            d.key[d.n] = yb_pairkey(L, c); d.sign[d.n++] = +1;
-        }
+    const uint32_t L = T(p - 1);
+    d.left = L < YB_PAD;
+    if (M(p - 2)) { // left neighbour is the b of the site at p-2: old pair (b,a), new pair (c,c)
+        d.lo = yb_pairkey(b, a);
+        d.ln = yb_pairkey(c, c);
+    } else {
+        d.lo = yb_pairkey(L, a);
+        d.ln = yb_pairkey(L, c);
     }
-    uint32_t R = T(p + 2);
-    if (R < YB_PAD && !M(p + 2)) { // if p+2 is a site, that site's left side covers this boundary
-        d.key[d.n] = yb_pairkey(b, R); d.sign[d.n++] = -1;
-        d.key[d.n] = yb_pairkey(c, R); d.sign[d.n++] = +1;
-    }
+    const uint32_t R = T(p + 2);
+    d.right = R < YB_PAD && !M(p + 2); // if p+2 is a site, that site's left side covers this boundary
+    d.ro = yb_pairkey(b, R);
+    d.rn = yb_pairkey(c, R);
 }
 
 // What position p of the old tile contributes to the rewritten tile.
@@ -86,3 +84,14 @@ YB_HD int yb_keep(int p, uint32_t c, bool drop_dead, TokF T, MrgF M, uint32_t &o
     bool pb = M(p - 3) ? false : (T(p - 2) >= YB_PAD);
     return !pb;
 }
+
+// Site-driven form of the same rewrite, used by k_apply (work proportional to the number of sites):
+// the only elements that leave a tile are the b of every site, PAD, and -- in the flat layout -- the two
+// remaining slots (c, SEP) of a word that was exactly (a b): it is now a single token and can never produce
+// a pair again.  This equals yb_keep() on a stream that holds no single-token / empty words, which the flat
+// loader guarantees (it never emits them) and this rule preserves.
+template <class TokF>
+YB_HD bool yb_site_word_dies(int p, TokF T) {
+    return T(p - 1) >= YB_PAD && T(p + 2) == YB_SEP;
+}
+

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tile_logic.h"
 
 namespace yb {
@@ -107,19 +109,23 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
 }
 
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
+// V = int for the flat layout (a workgroup's deltas fit 32 bits), unsigned long long for weighted words.
+template <class V>
 struct Agg {
     uint32_t *keys;
-    unsigned long long *vals;
+    V *vals;
 };
 
-__device__ __forceinline__ void agg_init(Agg g) {
+template <class V>
+__device__ __forceinline__ void agg_init(Agg<V> g) {
     for (int i = threadIdx.x; i < AGG_N; i += BLOCK) {
         g.keys[i] = EMPTY;
-        g.vals[i] = 0ull;
+        g.vals[i] = (V)0;
     }
 }
 
-__device__ __forceinline__ void agg_add(Agg g, const PairTable &t, DevState *st, uint32_t key, long long d) {
+template <class V>
+__device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *st, uint32_t key, long long d) {
     uint32_t s = hash32(key) & (AGG_N - 1);
 #pragma unroll 1
     for (int probe = 0; probe < 8; ++probe) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ void agg_add(Agg g, const PairTable &t, DevState *st,
             if (k == EMPTY) k = key;
         }
         if (k == key) {
-            atomicAdd(&g.vals[s], (unsigned long long)d);
+            atomicAdd(&g.vals[s], (V)d);
             return;
         }
         s = (s + 1) & (AGG_N - 1);
@@ -137,7 +143,28 @@ __device__ __forceinline__ void agg_add(Agg g, const PairTable &t, DevState *st,
     gt_add(t, st, key, d); // aggregator full around this hash: go straight to HBM
 }
 
-__device__ __forceinline__ void agg_flush(Agg g, const PairTable &t, DevState *st) {
+// Flat layout: lanes of one wave usually carry the same few keys (Zipf) -- peel the hottest keys off with
+// ballots so that one lane adds the wave's total instead of 64 lanes serialising on one LDS address.
+__device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, DevState *st, bool valid, uint32_t key,
+                                             int sign, int lane) {
+    unsigned long long pend = __ballot(valid);
+#pragma unroll 1
+    for (int r = 0; r < 3 && pend; ++r) {
+        const int leader = __ffsll((long long)pend) - 1;
+        const uint32_t k = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = valid && key == k;
+        const unsigned long long same = __ballot(mine);
+        const unsigned long long plus = __ballot(mine && sign > 0);
+        const int sum = __popcll(plus) - __popcll(same & ~plus);
+        if (lane == leader && sum != 0) agg_add(g, t, st, k, (long long)sum);
+        pend &= ~same;
+        if (mine) valid = false;
+    }
+    if (valid) agg_add(g, t, st, key, (long long)sign);
+}
+
+template <class V>
+__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st) {
     for (int i = threadIdx.x; i < AGG_N; i += BLOCK) {
         uint32_t k = g.keys[i];
         long long v = (long long)g.vals[i];
@@ -161,12 +188,12 @@ __device__ __forceinline__ TileRegs load_tile(const uint16_t *tiles, uint32_t ti
 }
 
 __device__ __forceinline__ bool match4(uint4 v, uint32_t nxt, uint32_t mk) {
-    bool m = (v.x == mk) | (v.y == mk) | (v.z == mk) | (v.w == mk);
-    m |= __builtin_amdgcn_alignbit(v.y, v.x, 16) == mk;
-    m |= __builtin_amdgcn_alignbit(v.z, v.y, 16) == mk;
-    m |= __builtin_amdgcn_alignbit(v.w, v.z, 16) == mk;
-    m |= __builtin_amdgcn_alignbit(nxt, v.w, 16) == mk;
-    return m;
+    int m = (v.x == mk) | (v.y == mk) | (v.z == mk) | (v.w == mk);
+    m |= (int)(__builtin_amdgcn_alignbit(v.y, v.x, 16) == mk);
+    m |= (int)(__builtin_amdgcn_alignbit(v.z, v.y, 16) == mk);
+    m |= (int)(__builtin_amdgcn_alignbit(v.w, v.z, 16) == mk);
+    m |= (int)(__builtin_amdgcn_alignbit(nxt, v.w, 16) == mk);
+    return m != 0;
 }
 
 // stage: [8 PAD][CAP slots][8 PAD]; position q lives at stage[8 + q]
@@ -195,7 +222,7 @@ __device__ __forceinline__ unsigned long long mark_sites(const uint16_t *stg, un
     if (a != b) {
         for (int k = 0; k < rounds; ++k) {
             int p = k * 64 + lane;
-            unsigned long long m = __ballot((T(p) == a) & (T(p + 1) == b));
+            unsigned long long m = __ballot((T(p) == a) && (T(p + 1) == b));
             if (lane == 0) mb[1 + k] = m;
             any |= m;
         }
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(CountParams P) {
     __shared__ uint32_t s_keys[AGG_N];
     __shared__ unsigned long long s_vals[AGG_N];
     __shared__ __attribute__((aligned(16))) uint16_t s_stage[WPB][8 + CAP + 8];
-    Agg agg{s_keys, s_vals};
+    Agg<unsigned long long> agg{s_keys, s_vals};
     agg_init(agg);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -285,97 +312,255 @@ struct ApplyParams {
     DevState *st;
 };
 
+// lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
+__device__ __forceinline__ uint32_t next_lane(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
+// bit j = "the pair starting at element j of this 8-slot segment equals (a,b)"
+__device__ __forceinline__ uint32_t match_mask8(uint4 v, uint32_t nxt, uint32_t mk) {
+    uint32_t m = (uint32_t)(v.x == mk);
+    m |= (uint32_t)(__builtin_amdgcn_alignbit(v.y, v.x, 16) == mk) << 1;
+    m |= (uint32_t)(v.y == mk) << 2;
+    m |= (uint32_t)(__builtin_amdgcn_alignbit(v.z, v.y, 16) == mk) << 3;
+    m |= (uint32_t)(v.z == mk) << 4;
+    m |= (uint32_t)(__builtin_amdgcn_alignbit(v.w, v.z, 16) == mk) << 5;
+    m |= (uint32_t)(v.w == mk) << 6;
+    m |= (uint32_t)(__builtin_amdgcn_alignbit(nxt, v.w, 16) == mk) << 7;
+    return m;
+}
+
+// bit j = "element j of this 8-slot segment equals the 16-bit value x"
+__device__ __forceinline__ uint32_t eq_mask8(uint4 v, uint32_t x) {
+    uint32_t m = (uint32_t)((v.x & 0xffffu) == x) | (uint32_t)((v.x >> 16) == x) << 1;
+    m |= (uint32_t)((v.y & 0xffffu) == x) << 2 | (uint32_t)((v.y >> 16) == x) << 3;
+    m |= (uint32_t)((v.z & 0xffffu) == x) << 4 | (uint32_t)((v.z >> 16) == x) << 5;
+    m |= (uint32_t)((v.w & 0xffffu) == x) << 6 | (uint32_t)((v.w >> 16) == x) << 7;
+    return m;
+}
+
+__device__ __forceinline__ uint32_t elem16(const uint4 &v, int j) {
+    const uint32_t d = (j >> 1) == 0 ? v.x : (j >> 1) == 1 ? v.y : (j >> 1) == 2 ? v.z : v.w;
+    return (j & 1) ? (d >> 16) : (d & 0xffffu);
+}
+
+// per-wave LDS scratch of the slow path
+struct WaveLds {
+    uint16_t stage[8 + CAP + 8];       // tokens with PAD halo; position q at stage[8 + q]
+    uint16_t out[CAP];                 // compacted tile
+    unsigned long long mb[CAP / 64 + 2]; // a == b only: site bitmap by 64-position rounds
+    uint32_t mbits[1 + CAP / 32 + 1];  // site bitmap, word w at mbits[1 + w], zero halo words
+    uint32_t dmask[CAP / 32 + 1];      // drop bitmap
+    uint32_t dpref[CAP / 32 + 1];      // exclusive popcount prefix of dmask
+    uint32_t smask[CAP / 32];          // weighted: SEP bitmap
+    uint32_t spref[CAP / 32];          // weighted: exclusive popcount prefix of smask
+};
+
+struct MrgBits {
+    const uint32_t *mbits;
+    __device__ __forceinline__ int operator()(int q) const { return (int)((mbits[1 + (q >> 5)] >> (q & 31)) & 1u); }
+};
+
+// exclusive prefix of popcounts over the 32 words of a bitmap (lanes 0..31 hold one word each)
+__device__ __forceinline__ uint32_t bitmap_prefix(uint32_t word, int lane, uint32_t *total) {
+    uint32_t pc = lane < 32 ? __popc(word) : 0u;
+    uint32_t inc = pc;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        uint32_t u = __shfl_up(inc, o);
+        if ((lane & 63) >= o) inc += u;
+    }
+    *total = __shfl(inc, 31);
+    return inc - pc;
+}
+
 template <bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     __shared__ uint32_t s_keys[AGG_N];
-    __shared__ unsigned long long s_vals[AGG_N];
-    __shared__ __attribute__((aligned(16))) uint16_t s_stage[WPB][8 + CAP + 8];
-    __shared__ __attribute__((aligned(16))) uint16_t s_out[WPB][CAP];
-    __shared__ unsigned long long s_mb[WPB][CAP / 64 + 2];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
 
     DevState *st = P.st;
     if (st->done | st->halt) return;
     const uint32_t a = st->a, b = st->b, c = st->c;
     const uint32_t mk = yb_memkey(a, b);
 
-    Agg agg{s_keys, s_vals};
+    Agg<AggV> agg{s_keys, s_vals};
     agg_init(agg);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint16_t *stg = s_stage[wib];
-    uint16_t *outb = s_out[wib];
-    unsigned long long *mb = s_mb[wib];
+    WaveLds &W = s_w[wib];
+    uint16_t *stg = W.stage;
     if (lane < 8) {
         stg[lane] = YB_PAD;
         stg[8 + CAP + lane] = YB_PAD;
     }
+    if (lane == 0) {
+        W.mbits[0] = 0;
+        W.mbits[1 + CAP / 32] = 0;
+    }
     __syncthreads();
     TokAt T{stg};
-    MrgAt M{mb};
+    MrgBits M{W.mbits};
 
     unsigned long long wave_sites = 0; // wave-uniform
     unsigned long long wave_freed = 0; // slots removed from this wave's tiles
     const uint32_t stride = gridDim.x * WPB;
-    for (uint32_t tile = blockIdx.x * WPB + wib; tile < P.n_tiles; tile += stride) {
-        const uint32_t len = P.tile_len[tile];
-        if (len == 0) continue;
-        TileRegs r = load_tile(P.tiles, tile, len, lane);
-        // ---- fast path: does any adjacent pair of this tile equal (a,b)?
-        uint32_t na = __shfl_down(r.va.x, 1);
-        uint32_t nb = __shfl_down(r.vb.x, 1);
-        uint32_t b0 = __shfl(r.vb.x, 0);
-        if (lane == 63) {
-            na = b0;
-            nb = PADPAD;
-        }
-        bool hit = match4(r.va, na, mk) | match4(r.vb, nb, mk);
-        if (!__any(hit)) continue;
+    const uint32_t n_tiles = P.n_tiles;
+    // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
+    // next tile's 2 x 16 B per lane are in flight while the current tile is examined.
+    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
+        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
+        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
+        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
+        TileRegs nxt = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t tile = batch + i * stride;
+            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
+            const TileRegs r = nxt;
+            if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
+            if (len == 0) continue;
+            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
 
-        // ---- slow path: this tile has at least one candidate site
-        wave_sync();
-        stage_tile(stg, r, lane);
-        wave_sync();
-        const int rounds = (len + 63) >> 6;
-        unsigned long long any = mark_sites(stg, mb, rounds, a, b, lane);
-        wave_sync();
-        if (!any) continue; // (a == b only: a lone candidate can lose to the parity rule -- never for a != b)
-
-        uint32_t outpos = 0;
-        uint32_t sep_carry = WEIGHTED ? P.tile_wbase[tile] : 0;
-        for (int k = 0; k < rounds; ++k) {
-            const int p = k * 64 + lane;
-            const unsigned long long mword = mb[1 + k];
-            uint32_t widx = 0;
+            // ---- slow path: work proportional to the number of sites in this tile
+            const int pA = lane * 8, pB = 512 + lane * 8; // first positions of this lane's two segments
+            wave_sync();
+            stage_tile(stg, r, lane);
+            uint32_t mA, mB; // site masks of the two segments
+            if (a != b) {
+                mA = match_mask8(r.va, na, mk);
+                mB = match_mask8(r.vb, nb, mk);
+            } else { // greedy parity rule over runs of a (trainer.py:276-285): through the round bitmaps
+                wave_sync();
+                const int rounds = (len + 63) >> 6;
+                const unsigned long long any = mark_sites(stg, W.mb, rounds, a, b, lane);
+                wave_sync();
+                if (!any) continue;
+                mA = (pA >> 6) < rounds ? (uint32_t)(W.mb[1 + (pA >> 6)] >> (pA & 63)) & 0xffu : 0u;
+                mB = (pB >> 6) < rounds ? (uint32_t)(W.mb[1 + (pB >> 6)] >> (pB & 63)) & 0xffu : 0u;
+            }
+            // site bitmap (for M(p-2), M(p+2) lookups) and cleared drop bitmap
+            reinterpret_cast<uint8_t *>(W.mbits + 1)[lane] = (uint8_t)mA;
+            reinterpret_cast<uint8_t *>(W.mbits + 1)[64 + lane] = (uint8_t)mB;
+            // PAD elements inside the live prefix leave the tile as well
+            uint32_t dA = eq_mask8(r.va, YB_PAD), dB = eq_mask8(r.vb, YB_PAD);
+            if ((uint32_t)pA + 8 > len) dA &= (uint32_t)pA < len ? (1u << (len - pA)) - 1u : 0u;
+            if ((uint32_t)pB + 8 > len) dB &= (uint32_t)pB < len ? (1u << (len - pB)) - 1u : 0u;
+            reinterpret_cast<uint8_t *>(W.dmask)[lane] = (uint8_t)dA;
+            reinterpret_cast<uint8_t *>(W.dmask)[64 + lane] = (uint8_t)dB;
+            if (lane == 0) W.dmask[CAP / 32] = 0;
+            uint32_t wbase = 0;
             if (WEIGHTED) {
-                unsigned long long sm = __ballot(T(p) == YB_SEP);
-                widx = sep_carry + __popcll(sm & lanemask_lt(lane));
-                sep_carry += __popcll(sm);
+                reinterpret_cast<uint8_t *>(W.smask)[lane] = (uint8_t)eq_mask8(r.va, YB_SEP);
+                reinterpret_cast<uint8_t *>(W.smask)[64 + lane] = (uint8_t)eq_mask8(r.vb, YB_SEP);
+                wbase = P.tile_wbase[tile];
             }
-            if (mword) {
-                if ((mword >> lane) & 1ull) {
-                    YbDeltas d;
+            wave_sync();
+            if (WEIGHTED) {
+                uint32_t tot;
+                uint32_t pre = bitmap_prefix(lane < 32 ? W.smask[lane & 31] : 0u, lane, &tot);
+                if (lane < 32) W.spref[lane] = pre;
+                wave_sync();
+            }
+            // ---- deltas + drop marks: each lane walks its own sites (usually none or one)
+            uint32_t mm = mA | (mB << 8);
+            {
+                uint32_t tot = __popc(mm);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+                wave_sites += tot;
+            }
+            while (__any(mm != 0)) {
+                const bool site = mm != 0;
+                const int j = site ? (__ffs((int)mm) - 1) : 0;
+                mm &= mm - 1;
+                const int p = j < 8 ? pA + j : pB + (j - 8);
+                YbDeltas d;
+                d.left = d.right = false;
+                d.lo = d.ln = d.ro = d.rn = 0;
+                if (site) {
                     yb_site_deltas(p, a, b, c, T, M, d);
-                    long long w = WEIGHTED ? (long long)P.wfreq[widx] : 1;
-                    for (int i = 0; i < d.n; ++i) agg_add(agg, P.out, st, d.key[i], d.sign[i] * w);
-                    if (WEIGHTED) agg_add(agg, P.out, st, yb_pairkey(a, b), -w);
+                    atomicOr(&W.dmask[(p + 1) >> 5], 1u << ((p + 1) & 31));
+                    if (!WEIGHTED && yb_site_word_dies(p, T)) {
+                        atomicOr(&W.dmask[p >> 5], 1u << (p & 31));
+                        atomicOr(&W.dmask[(p + 2) >> 5], 1u << ((p + 2) & 31));
+                    }
                 }
-                wave_sites += __popcll(mword);
+                if constexpr (WEIGHTED) {
+                    if (site) {
+                        const uint32_t sw = W.smask[p >> 5];
+                        const uint32_t widx = wbase + W.spref[p >> 5] + __popc(sw & ((1u << (p & 31)) - 1u));
+                        const long long w = (long long)P.wfreq[widx];
+                        if (d.left) {
+                            agg_add(agg, P.out, st, d.lo, -w);
+                            agg_add(agg, P.out, st, d.ln, +w);
+                        }
+                        if (d.right) {
+                            agg_add(agg, P.out, st, d.ro, -w);
+                            agg_add(agg, P.out, st, d.rn, +w);
+                        }
+                        agg_add(agg, P.out, st, yb_pairkey(a, b), -w);
+                    }
+                } else {
+                    agg_add_wave(agg, P.out, st, d.left, d.lo, -1, lane);
+                    agg_add_wave(agg, P.out, st, d.left, d.ln, +1, lane);
+                    agg_add_wave(agg, P.out, st, d.right, d.ro, -1, lane);
+                    agg_add_wave(agg, P.out, st, d.right, d.rn, +1, lane);
+                }
             }
-            uint32_t o = 0;
-            int keep = yb_keep(p, c, !WEIGHTED, T, M, o);
-            unsigned long long km = __ballot(keep);
-            if (keep) outb[outpos + __popcll(km & lanemask_lt(lane))] = (uint16_t)o;
-            outpos += __popcll(km);
+            wave_sync();
+            // ---- compaction: every kept element moves left by the number of dropped elements before it
+            uint32_t dropped;
+            {
+                uint32_t pre = bitmap_prefix(lane < 32 ? W.dmask[lane & 31] : 0u, lane, &dropped);
+                if (lane < 32) W.dpref[lane] = pre;
+            }
+            wave_sync();
+            const uint32_t new_len = len - dropped;
+            uint32_t first_drop = CAP; // first changed position: 16-B groups before it are unchanged in HBM
+            {
+                const uint32_t dw = lane < 32 ? W.dmask[lane & 31] : 0u;
+                const unsigned long long nz = __ballot(dw != 0);
+                if (nz) {
+                    const int wl = __ffsll((long long)nz) - 1;
+                    first_drop = wl * 32 + (__ffs((int)__shfl(dw, wl)) - 1);
+                }
+                // a site at p rewrites slot p (a -> c) and drops p+1: the first CHANGED slot can be first_drop - 1
+                if (first_drop > 0) first_drop -= 1;
+            }
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg) {
+                const int p0 = seg ? pB : pA;
+                if ((uint32_t)p0 < len && (uint32_t)p0 + 8 > first_drop) {
+                    const uint4 &v = seg ? r.vb : r.va;
+                    const uint32_t sm = seg ? mB : mA;
+                    const uint32_t dw = W.dmask[p0 >> 5];
+                    uint32_t shift = W.dpref[p0 >> 5] + __popc(dw & ((1u << (p0 & 31)) - 1u));
+                    const uint32_t db = (dw >> (p0 & 31)) & 0xffu;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((db >> j) & 1u) {
+                            ++shift;
+                        } else if ((uint32_t)(p0 + j) < len) {
+                            W.out[p0 + j - shift] = (uint16_t)(((sm >> j) & 1u) ? c : elem16(v, j));
+                        }
+                    }
+                }
+            }
+            const uint32_t pad_end = (new_len + 7u) & ~7u;
+            if (lane < 8 && new_len + lane < pad_end) W.out[new_len + lane] = YB_PAD;
+            wave_sync();
+            uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+            if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(W.out + pA);
+            if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(W.out + pB);
+            if (lane == 0) P.tile_len[tile] = new_len;
+            wave_freed += dropped;
         }
-        const uint32_t new_len = outpos;
-        const uint32_t pad_end = (new_len + 7u) & ~7u;
-        if (lane < 8 && new_len + lane < pad_end) outb[new_len + lane] = YB_PAD;
-        wave_sync();
-        uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-        if ((uint32_t)(lane * 8) < new_len) wb[lane] = *reinterpret_cast<const uint4 *>(outb + lane * 8);
-        if ((uint32_t)(512 + lane * 8) < new_len) wb[64 + lane] = *reinterpret_cast<const uint4 *>(outb + 512 + lane * 8);
-        if (lane == 0) P.tile_len[tile] = new_len;
-        wave_freed += len - new_len;
     }
     if (lane == 0) {
         if (wave_sites) {
@@ -756,13 +941,17 @@ __global__ __launch_bounds__(BLOCK) void k_load_words(LoadParams P) {
     const unsigned long long tile = pos / SPAN;
     const uint32_t slot = (uint32_t)(pos - tile * SPAN);
     uint16_t *dst = P.tiles + tile * CAP + slot;
-    if (P.tile_wbase) atomicMin(&P.tile_wbase[tile], (uint32_t)w);
+    const bool weighted = P.tile_wbase != nullptr;
+    if (weighted) atomicMin(&P.tile_wbase[tile], (uint32_t)w);
+    if (!weighted && L <= 1) return; // flat layout: a word of < 2 tokens can never form a pair (trainer.py:231)
     if (L + 1 > (unsigned long long)LMAX) {
         uint32_t idx = atomicAdd(P.long_count, 1u);
         if (idx < P.long_cap) P.long_word[idx] = (uint32_t)w;
         atomicAdd(P.long_total, L);
-        dst[0] = YB_SEP; // placeholder keeps word indices aligned
-        atomicMax(&P.tile_len[tile], slot + 1);
+        if (weighted) {
+            dst[0] = YB_SEP; // placeholder keeps word indices aligned
+            atomicMax(&P.tile_len[tile], slot + 1);
+        }
         return;
     }
     const uint8_t *src = P.bytes + o0;
