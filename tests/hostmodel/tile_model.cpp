@@ -30,9 +30,13 @@ struct Model {
     std::vector<uint32_t> m_left, m_right, m_merged;
     std::vector<uint64_t> m_count;
     bool keep_mismatch = false;
+    uint32_t cur_key = 0xFFFFFFFFu;
 };
 
-void add_delta(Model &m, uint32_t key, int64_t d) { m.table[key] += d; }
+void add_delta(Model &m, uint32_t key, int64_t d) {
+    if (key == m.cur_key) return;  // the merged pair's count becomes exactly 0: zeroed at selection, never updated
+    m.table[key] += d;
+}
 
 void count_all(Model &m) {
     m.table.clear();
@@ -215,8 +219,11 @@ int tile_model_train(const uint8_t *bytes, const uint64_t *off, const uint64_t *
         auto f = m.vocab.find(mb);
         if (f != m.vocab.end()) c = f->second;
         else { c = (uint32_t)m.tok.size(); m.tok.push_back(mb); m.vocab[mb] = c; }
+        m.cur_key = bk;
+        m.table[bk] = 0;
         for (size_t t = 0; t < m.tiles.size(); t++) apply_tile(m, t, a, b, c);
         for (size_t i = 0; i < m.longw.size(); i++) apply_long(m, i, a, b, c);
+        m.cur_key = 0xFFFFFFFFu;
         out_left[done] = a; out_right[done] = b; out_merged[done] = c; out_count[done] = (uint64_t)bc;
         done++;
         if (m.keep_mismatch) return -2000000 - (int)it;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_stream(const uint4* p, size_t n, uint32
     if (m) atomicAdd(hits, 1u);
 }
 
-template <int DEPTH, int LDS_BYTES>
+template <int DEPTH, int LDS_BYTES, int ATOM>
 __global__ __launch_bounds__(256) void k_tiles(const uint16_t* tiles, const uint32_t* tile_len, uint32_t n_tiles, uint32_t mk, unsigned* hits) {
     __shared__ uint32_t lds[LDS_BYTES / 4 > 0 ? LDS_BYTES / 4 : 1];
     if (LDS_BYTES > 0 && threadIdx.x == 0 && mk == 0x12345) lds[n_tiles % (LDS_BYTES / 4)] = 1;  // keep the allocation
@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void k_tiles(const uint16_t* tiles, const uint
         }
     }
     if (found && lane == 0) atomicAdd(hits, found);
+    if (ATOM == 1 && lane == 0) { atomicAdd(hits + 2, 1u); atomicAdd((unsigned long long*)(hits + 4), 1ull); }
+    if (ATOM == 2 && threadIdx.x == 0) { atomicAdd(hits + 2, 1u); atomicAdd((unsigned long long*)(hits + 4), 1ull); }
+    if (ATOM == 3 && threadIdx.x < 4) { atomicAdd((unsigned long long*)(hits + 4 + 2 * threadIdx.x), 1ull); }
     if (LDS_BYTES > 0 && mk == 0x12345) hits[1] = lds[0];
 }
 
@@ -114,10 +117,10 @@ int main(int argc, char** argv) {
         float ms = time_it([&] { hipLaunchKernelGGL(k_stream, dim3(g), dim3(256), 0, 0, (const uint4*)d_tiles, n16 / 8, mk, d_hits); });
         printf("stream      grid %5d : %7.3f ms  %7.1f GB/s\n", g, ms, (double)n16 * 2 / ms / 1e6);
     }
-#define RUN(D, L) for (int g : {1280, 1536, 2048, 2560, 4096}) { \
-        float ms = time_it([&] { hipLaunchKernelGGL((k_tiles<D, L>), dim3(g), dim3(256), 0, 0, d_tiles, d_len, n_tiles, mk, d_hits); }); \
-        printf("tiles D=%d LDS=%5d grid %5d : %7.3f ms  %7.1f GB/s\n", D, L, g, ms, bytes / ms / 1e6); }
-    RUN(1, 0) RUN(1, 25600) RUN(2, 0) RUN(2, 25600) RUN(3, 0) RUN(4, 0) RUN(4, 25600) RUN(4, 17408)
+#define RUN(D, L, A) for (int g : {1280, 2560}) { \
+        float ms = time_it([&] { hipLaunchKernelGGL((k_tiles<D, L, A>), dim3(g), dim3(256), 0, 0, d_tiles, d_len, n_tiles, mk, d_hits); }); \
+        printf("tiles D=%d LDS=%5d ATOM=%d grid %5d : %7.3f ms  %7.1f GB/s\n", D, L, A, g, ms, bytes / ms / 1e6); }
+    RUN(1, 25600, 0) RUN(1, 25600, 1) RUN(1, 25600, 2) RUN(1, 25600, 3) RUN(2, 25600, 0)
     unsigned hh[2]; CK(hipMemcpy(hh, d_hits, 8, hipMemcpyDeviceToHost));
     printf("hits %u\n", hh[0]);
     return 0;

@@ -24,6 +24,7 @@ using namespace yb;
 
 namespace {
 
+constexpr uint32_t MAX_APPLY_BLOCKS = 8192;
 thread_local std::string g_create_error;
 
 struct EventPair {
@@ -80,6 +81,7 @@ struct yabpe_ctx {
     std::vector<void *> synth_bufs;
     // misc device scratch
     unsigned long long *scratch64 = nullptr;  // 8 x u64
+    unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
 };
 
 namespace {
@@ -187,7 +189,14 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
 uint32_t count_grid(yabpe_ctx *c) {
     uint32_t want = (c->n_tiles + WPB - 1) / WPB;
     uint32_t cap = (uint32_t)optv(c, "apply_blocks", (int64_t)c->n_cu * 5);
-    return std::max(1u, std::min(want, cap));
+    return std::max(1u, std::min(std::min(want, cap), MAX_APPLY_BLOCKS));
+}
+
+int fold_stats(yabpe_ctx *c) {
+    FoldParams F{c->st, c->blk_stats, MAX_APPLY_BLOCKS};
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(BLOCK), 0, c->stream, F);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 // full recount of the resident stream into `t` (zeroed by the caller)
@@ -347,12 +356,14 @@ int yabpe_create(yabpe_ctx **out, int device_id) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&c->st, sizeof(DevState)) != hipSuccess ||
         hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void **)&c->scratch64, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&c->scratch64, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->blk_stats, 2 * MAX_APPLY_BLOCKS * sizeof(unsigned long long)) != hipSuccess) {
         int code = fail(nullptr, YABPE_E_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
         yabpe_destroy(c);
         return code;
     }
     (void)hipMemset(c->st, 0, sizeof(DevState));
+    (void)hipMemset(c->blk_stats, 0, 2 * MAX_APPLY_BLOCKS * sizeof(unsigned long long));
     memset(c->st_host, 0, sizeof(DevState));
     *out = c;
     return YABPE_OK;
@@ -369,6 +380,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->partials);
     dfree(c->st);
     dfree(c->scratch64);
+    dfree(c->blk_stats);
     if (c->st_host) (void)hipHostFree(c->st_host);
     for (auto &e : c->events) {
         (void)hipEventDestroy(e.e0);
@@ -613,13 +625,13 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
     hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
     SelectParams S{c->partials, c->n_partials, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
-                   c->rec_count, c->rec_sites, c->rec_live, rec_base};
+                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table, c->blk_stats, MAX_APPLY_BLOCKS};
     hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
     hipLaunchKernelGGL(k_rank_update, dim3(cdiv64(tokens_upper, BLOCK)), dim3(BLOCK), 0, c->stream, R);
     if (ev) HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     if (c->n_tiles) {
-        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->table, c->st};
+        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->table, c->st, c->blk_stats};
         if (c->weighted)
             hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
         else
@@ -709,6 +721,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             }
             TRY(launch_iteration(c, rec_base, tokens_start + i + 1, apply_grid, ev));
         }
+        TRY(fold_stats(c));
         TRY(state_pull(c));
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
         if (h->halt) {

@@ -64,8 +64,10 @@ struct PairTable {
 
 struct Best {
     unsigned long long cnt;
-    uint32_t rk;  // lexrank[left] << 16 | lexrank[right]
-    uint32_t key; // left << 16 | right
+    uint32_t rk;   // lexrank[left] << 16 | lexrank[right]
+    uint32_t key;  // left << 16 | right
+    uint32_t slot; // table slot of the entry
+    uint32_t pad;
 };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t k) {
@@ -310,6 +312,7 @@ struct ApplyParams {
     uint32_t n_tiles;
     PairTable out; // where deltas go: the pair table (1 GPU) or the per-rank delta table (multi-GPU)
     DevState *st;
+    unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
 };
 
 // lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
@@ -381,13 +384,17 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
     __shared__ AggV s_vals[AGG_N];
     __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
 
+    __shared__ unsigned long long s_cnt[2];
+
     DevState *st = P.st;
     if (st->done | st->halt) return;
     const uint32_t a = st->a, b = st->b, c = st->c;
     const uint32_t mk = yb_memkey(a, b);
+    const uint32_t self = yb_pairkey(a, b); // its count was set to 0 by k_select: never updated here
 
     Agg<AggV> agg{s_keys, s_vals};
     agg_init(agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds &W = s_w[wib];
@@ -497,19 +504,18 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
                         const uint32_t widx = wbase + W.spref[p >> 5] + __popc(sw & ((1u << (p & 31)) - 1u));
                         const long long w = (long long)P.wfreq[widx];
                         if (d.left) {
-                            agg_add(agg, P.out, st, d.lo, -w);
+                            if (d.lo != self) agg_add(agg, P.out, st, d.lo, -w);
                             agg_add(agg, P.out, st, d.ln, +w);
                         }
                         if (d.right) {
-                            agg_add(agg, P.out, st, d.ro, -w);
+                            if (d.ro != self) agg_add(agg, P.out, st, d.ro, -w);
                             agg_add(agg, P.out, st, d.rn, +w);
                         }
-                        agg_add(agg, P.out, st, yb_pairkey(a, b), -w);
                     }
                 } else {
-                    agg_add_wave(agg, P.out, st, d.left, d.lo, -1, lane);
+                    agg_add_wave(agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane);
                     agg_add_wave(agg, P.out, st, d.left, d.ln, +1, lane);
-                    agg_add_wave(agg, P.out, st, d.right, d.ro, -1, lane);
+                    agg_add_wave(agg, P.out, st, d.right && d.ro != self, d.ro, -1, lane);
                     agg_add_wave(agg, P.out, st, d.right, d.rn, +1, lane);
                 }
             }
@@ -563,13 +569,14 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
         }
     }
     if (lane == 0) {
-        if (wave_sites) {
-            if (!WEIGHTED) agg_add(agg, P.out, st, yb_pairkey(a, b), -(long long)wave_sites);
-            atomicAdd(&st->sites, wave_sites);
-        }
-        if (wave_freed) atomicAdd(&st->live_slots, (unsigned long long)(-(long long)wave_freed));
+        if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
+        if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
     }
     __syncthreads();
+    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // plain stores; k_select / k_fold_stats sum and clear them
+        P.blk_stats[2 * blockIdx.x] = s_cnt[0];
+        P.blk_stats[2 * blockIdx.x + 1] = s_cnt[1];
+    }
     agg_flush(agg, P.out, st);
 }
 
@@ -602,6 +609,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     const uint32_t i = blockIdx.x;
     if (i >= P.n_long) return;
     const uint32_t a = st->a, b = st->b, c = st->c;
+    const uint32_t self = yb_pairkey(a, b);
     uint16_t *t = P.tok + P.off[i];
     const uint32_t len = P.len[i];
     const long long w = P.freq ? (long long)P.freq[i] : 1;
@@ -628,15 +636,15 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
             uint32_t q = 0, no = 0;
             while (q < (uint32_t)LONG_CH && j + q < len) {
                 if (j + q + 1 < len && s_in[q] == a && s_in[q + 1] == b) {
+                    // (deltas to the merged pair's own key are skipped: k_select set its count to 0)
                     if (have_prev) {
-                        gt_add(P.out, st, yb_pairkey(prev_old, a), -w);
+                        if (yb_pairkey(prev_old, a) != self) gt_add(P.out, st, yb_pairkey(prev_old, a), -w);
                         gt_add(P.out, st, yb_pairkey(prev_new, c), +w);
                     }
-                    gt_add(P.out, st, yb_pairkey(a, b), -w);
                     if (j + q + 2 < len) {
                         bool next_site = (j + q + 3 < len) && s_in[q + 2] == a && s_in[q + 3] == b;
                         if (!next_site) {
-                            gt_add(P.out, st, yb_pairkey(b, s_in[q + 2]), -w);
+                            if (yb_pairkey(b, s_in[q + 2]) != self) gt_add(P.out, st, yb_pairkey(b, s_in[q + 2]), -w);
                             gt_add(P.out, st, yb_pairkey(c, s_in[q + 2]), +w);
                         }
                     }
@@ -685,6 +693,8 @@ __device__ __forceinline__ Best best_wave_reduce(Best v) {
         u.cnt = __shfl_xor(v.cnt, o);
         u.rk = __shfl_xor(v.rk, o);
         u.key = __shfl_xor(v.key, o);
+        u.slot = __shfl_xor(v.slot, o);
+        u.pad = 0;
         if (best_gt(u, v)) v = u;
     }
     return v;
@@ -700,14 +710,14 @@ struct ArgmaxParams {
 __global__ __launch_bounds__(BLOCK) void k_argmax_partial(ArgmaxParams P) {
     __shared__ Best s_b[WPB];
     if (P.st->done | P.st->halt) return;
-    Best best{0ull, 0u, EMPTY};
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
     const uint32_t cap = P.table.mask + 1;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
         uint32_t k = P.table.keys[s];
         if (k == EMPTY) continue;
         long long cn = (long long)P.table.cnt[s];
         if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
-        Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k};
+        Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
         if (best_gt(e, best)) best = e;
     }
     best = best_wave_reduce(best);
@@ -768,7 +778,46 @@ struct SelectParams {
     unsigned long long *rec_sites;      // sites merged by iteration i (written when iteration i+1 is selected)
     unsigned long long *rec_live_slots; // live slots read by iteration i's apply pass
     uint32_t rec_base;                  // iter value at the start of this yabpe_train call
+    PairTable table;                    // the selected pair's entry is zeroed here
+    unsigned long long *blk_stats;      // per-workgroup counters of the last k_apply
+    uint32_t n_blk;
 };
+
+// Adds the per-workgroup counters of the last apply pass to DevState and clears them (one workgroup).
+__device__ __forceinline__ void fold_block_stats(DevState *st, unsigned long long *blk, uint32_t n_blk) {
+    __shared__ unsigned long long s_fold[2];
+    if (threadIdx.x < 2) s_fold[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long a = 0, f = 0;
+    for (uint32_t i = threadIdx.x; i < n_blk; i += BLOCK) {
+        a += blk[2 * i];
+        f += blk[2 * i + 1];
+        blk[2 * i] = 0;
+        blk[2 * i + 1] = 0;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        f += __shfl_xor(f, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (a | f)) {
+        atomicAdd(&s_fold[0], a);
+        atomicAdd(&s_fold[1], f);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->sites += s_fold[0];
+        st->live_slots -= s_fold[1];
+    }
+    __syncthreads();
+}
+
+struct FoldParams {
+    DevState *st;
+    unsigned long long *blk_stats;
+    uint32_t n_blk;
+};
+__global__ __launch_bounds__(BLOCK) void k_fold_stats(FoldParams P) { fold_block_stats(P.st, P.blk_stats, P.n_blk); }
+
 
 __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
     __shared__ Best s_b[BLOCK];
@@ -780,8 +829,9 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         s_flag = st->done | st->halt;
     }
     __syncthreads();
+    fold_block_stats(st, P.blk_stats, P.n_blk);
     if (s_flag) return;
-    Best best{0ull, 0u, EMPTY};
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK)
         if (best_gt(P.partials[i], best)) best = P.partials[i];
     s_b[tid] = best;
@@ -878,6 +928,9 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         P.rec_merged[ri] = cid;
         P.rec_count[ri] = s_b[0].cnt;
         P.rec_live_slots[ri] = st->live_slots;
+        // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
+        // set it here once instead of letting every workgroup subtract its share from one hot address
+        P.table.cnt[s_b[0].slot] = 0ull;
         st->a = x;
         st->b = y;
         st->c = cid;
