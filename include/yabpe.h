@@ -99,15 +99,24 @@ typedef struct yabpe_stats_t {
     uint64_t retiles, table_rebuilds;
     double load_ms;            /* yabpe_load_words device time */
     double train_ms;           /* device time of all yabpe_train calls (event-timed) */
-    double apply_ms_sampled;   /* sum of event-timed apply launches ("event_sample") */
+    double apply_ms_sampled;   /* sum of the event-timed apply phases (k_apply, or k_scan + k_slow) */
     uint64_t apply_launches_sampled;
     uint64_t apply_algo_bytes_sampled;   /* sum of 2*(T_i + W) over the sampled launches */
     uint64_t apply_actual_bytes_sampled; /* sum of 2*live_slots over the sampled launches */
     uint64_t algo_bytes_total;           /* sum over all iterations of 2*(T_i + W) */
+    /* split form only: the streaming scan kernel (k_scan) by itself */
+    double scan_ms_sampled;
+    uint64_t scan_launches_sampled;
+    uint64_t scan_algo_bytes_sampled;
+    uint64_t scan_actual_bytes_sampled;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */
 int yabpe_iter_log(yabpe_ctx *ctx, uint64_t *out_sites, uint64_t *out_live_slots, uint32_t cap, uint32_t *out_n);
+
+/* Per-launch HIP-event timings of k_apply from the last yabpe_train call (option "event_sample" = N times every
+   Nth launch): iteration index (relative to the call) and duration in microseconds. */
+int yabpe_event_log(yabpe_ctx *ctx, uint32_t *out_iter, float *out_us, uint32_t cap, uint32_t *out_n);
 
 /* Debug / self-check: recount every pair from the token stream into a scratch table and compare with the
    incrementally maintained table.  *out_mismatches = number of differing keys. */

@@ -24,9 +24,11 @@
  * Tokens are canonical ids: one id per distinct byte string, so id equality is
  * byte-string equality, which is what the reference's tuple-of-bytes words compare.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef struct {
     uint8_t *ptr;
@@ -204,7 +206,10 @@ typedef struct {
 
 oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint64_t n_words,
                                 const uint8_t *sp_bytes, const uint32_t *sp_off, uint32_t n_specials,
-                                uint64_t vocab_size, uint64_t min_frequency) {
+                                uint64_t vocab_size, uint64_t min_frequency, double max_seconds) {
+    /* max_seconds > 0 bounds the merge loop's wall time (bench.py's cpu_baseline leg); 0 = run to the end */
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     oracle_result *r = (oracle_result *)calloc(1, sizeof(oracle_result));
     r->cap_toks = 1024;
     r->toks = (tok_t *)malloc(sizeof(tok_t) * r->cap_toks);
@@ -305,6 +310,11 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
     uint32_t scratch_cap = 0;
 
     for (uint64_t it = 0; it < num_merges; it++) {
+        if (max_seconds > 0 && (it & 15) == 0) {
+            struct timespec ts1;
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            if ((ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec) > max_seconds) break;
+        }
         /* argmax (trainer.py:246): max over (count, (bytes(p0), bytes(p1))); only count > 0 exist */
         pair_t *best = NULL;
         for (uint64_t s = 0; s < pt.cap; s++) {

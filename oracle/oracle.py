@@ -34,7 +34,7 @@ def _lib() -> ctypes.CDLL:
         lib = ctypes.CDLL(str(build()))
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         lib.bpe_oracle_train.restype = vp
-        lib.bpe_oracle_train.argtypes = [vp, vp, u64, vp, vp, u32, u64, u64]
+        lib.bpe_oracle_train.argtypes = [vp, vp, u64, vp, vp, u32, u64, u64, ctypes.c_double]
         for name in ("bpe_oracle_n_merges", "bpe_oracle_n_tokens"):
             getattr(lib, name).restype = u32
             getattr(lib, name).argtypes = [vp]
@@ -63,7 +63,7 @@ def flatten(sequences) -> tuple[np.ndarray, np.ndarray]:
 
 
 def train_flat(flat: np.ndarray, off: np.ndarray, vocab_size: int, min_frequency: int, special_tokens,
-               return_ids: bool = False):
+               return_ids: bool = False, max_seconds: float = 0.0):
     """Run the C oracle on flat words.  Returns (vocab: dict[bytes,int], merges: list[(bytes,bytes)])
     exactly as BBPETrainer._merge_loop does (trainer.py:302); with return_ids also the id triples/counts."""
     lib = _lib()
@@ -76,7 +76,7 @@ def train_flat(flat: np.ndarray, off: np.ndarray, vocab_size: int, min_frequency
     if sp:
         sp_off[1:] = np.cumsum([len(t) for t in sp])
     h = lib.bpe_oracle_train(flat.ctypes.data if flat.size else None, off.ctypes.data, n_words,
-                             sp_bytes.ctypes.data, sp_off.ctypes.data, len(sp), int(vocab_size), int(min_frequency))
+                             sp_bytes.ctypes.data, sp_off.ctypes.data, len(sp), int(vocab_size), int(min_frequency), float(max_seconds))
     try:
         nm = lib.bpe_oracle_n_merges(h)
         nt = lib.bpe_oracle_n_tokens(h)

@@ -28,8 +28,9 @@ constexpr uint32_t MAX_APPLY_BLOCKS = 8192;
 thread_local std::string g_create_error;
 
 struct EventPair {
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1, e2;  // before the apply phase, after its streaming kernel, after its last kernel
     uint32_t iter_rel;
+    bool split;
 };
 
 }  // namespace
@@ -74,6 +75,8 @@ struct yabpe_ctx {
     uint32_t *rec_left = nullptr, *rec_right = nullptr, *rec_merged = nullptr;
     unsigned long long *rec_count = nullptr, *rec_sites = nullptr, *rec_live = nullptr;
     std::vector<uint64_t> log_sites, log_live;
+    std::vector<uint32_t> ev_iter;
+    std::vector<float> ev_us;
     // stats
     yabpe_stats_t stats{};
     std::vector<EventPair> events;
@@ -82,6 +85,12 @@ struct yabpe_ctx {
     // misc device scratch
     unsigned long long *scratch64 = nullptr;  // 8 x u64
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
+    uint32_t blk_used = 0;                    // largest grid that wrote blk_stats
+    // split apply: worklist of tiles that contain the pair
+    uint32_t *work = nullptr, *work_cnt = nullptr;
+    uint64_t work_cap = 0;
+    bool split_mode = false;
+    std::vector<float> ev_scan_us;
 };
 
 namespace {
@@ -193,7 +202,7 @@ uint32_t count_grid(yabpe_ctx *c) {
 }
 
 int fold_stats(yabpe_ctx *c) {
-    FoldParams F{c->st, c->blk_stats, MAX_APPLY_BLOCKS};
+    FoldParams F{c->st, c->blk_stats, std::max(c->blk_used, 1u)};
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(BLOCK), 0, c->stream, F);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -217,7 +226,7 @@ int launch_count(yabpe_ctx *c, PairTable t) {
     return 0;
 }
 
-// (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/4.
+// (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
 int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
     for (int attempt = 0; attempt < 16; ++attempt) {
@@ -228,7 +237,7 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
         c->table_cap = cap;
         TRY(launch_count(c, c->table));
         TRY(state_pull(c));
-        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 4 <= cap) {
+        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 2 <= cap) {
             c->stats.table_rebuilds++;
             return 0;
         }
@@ -236,6 +245,31 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
         if (cap > (1ull << 31)) break;
     }
     return fail(c, YABPE_E_CAPACITY, "pair table does not fit (more than 2^29 distinct pairs)");
+}
+
+// Grow the pair table by re-inserting its live entries (entries whose count fell to 0 are dropped).
+int table_grow(yabpe_ctx *c, uint64_t new_cap) {
+    for (int attempt = 0; attempt < 8; ++attempt, new_cap *= 2) {
+        PairTable nt{};
+        HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
+        TRY(table_alloc(c, nt, new_cap, &c->st->table_entries));
+        RehashParams R{c->table, nt, c->st};
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(1, c->table_cap / BLOCK));
+        hipLaunchKernelGGL(k_rehash, dim3(grid), dim3(BLOCK), 0, c->stream, R);
+        HIPCHK(c, hipGetLastError());
+        TRY(state_pull(c));
+        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 2 <= new_cap) {
+            table_free(c->table);
+            c->table = nt;
+            c->table_cap = new_cap;
+            c->stats.table_rebuilds++;
+            return 0;
+        }
+        table_free(nt);
+        c->st_host->halt_req = 0;
+        TRY(state_push(c));
+    }
+    return fail(c, YABPE_E_CAPACITY, "pair table does not fit");
 }
 
 int refresh_live_slots(yabpe_ctx *c) {
@@ -381,10 +415,13 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->st);
     dfree(c->scratch64);
     dfree(c->blk_stats);
+    dfree(c->work);
+    dfree(c->work_cnt);
     if (c->st_host) (void)hipHostFree(c->st_host);
     for (auto &e : c->events) {
         (void)hipEventDestroy(e.e0);
         (void)hipEventDestroy(e.e1);
+        (void)hipEventDestroy(e.e2);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -615,29 +652,73 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.apply_launches_sampled = 0;
     c->stats.apply_algo_bytes_sampled = 0;
     c->stats.apply_actual_bytes_sampled = 0;
+    c->stats.scan_ms_sampled = 0;
+    c->stats.scan_launches_sampled = 0;
+    c->stats.scan_algo_bytes_sampled = 0;
+    c->stats.scan_actual_bytes_sampled = 0;
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
     return YABPE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- train
+static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
+    const uint64_t need = (uint64_t)scan_grid * seg;
+    if (need > c->work_cap || !c->work) {
+        dfree(c->work);
+        c->work = nullptr;
+        TRY(dmalloc(c, &c->work, need));
+        c->work_cap = need;
+    }
+    if (!c->work_cnt) {
+        TRY(dmalloc(c, &c->work_cnt, MAX_LISTS));
+        HIPCHK(c, hipMemsetAsync(c->work_cnt, 0, MAX_LISTS * 4, c->stream));
+    }
+    return 0;
+}
+
 static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev) {
     ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
     hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
     SelectParams S{c->partials, c->n_partials, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
-                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table, c->blk_stats, MAX_APPLY_BLOCKS};
+                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table, c->blk_stats, std::max(c->blk_used, 1u)};
     hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
     hipLaunchKernelGGL(k_rank_update, dim3(cdiv64(tokens_upper, BLOCK)), dim3(BLOCK), 0, c->stream, R);
-    if (ev) HIPCHK(c, hipEventRecord(ev->e0, c->stream));
+    if (ev) {
+        ev->split = c->split_mode;
+        HIPCHK(c, hipEventRecord(ev->e0, c->stream));
+    }
     if (c->n_tiles) {
         ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->table, c->st, c->blk_stats};
-        if (c->weighted)
-            hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
-        else
-            hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+        if (!c->split_mode) {
+            c->blk_used = std::max(c->blk_used, apply_grid);
+            if (c->weighted)
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+            else
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+            if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+        } else {
+            // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
+            const uint32_t want = (c->n_tiles + WPB - 1) / WPB;
+            const uint32_t scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 8)), MAX_LISTS));
+            const uint32_t seg = WPB * ((c->n_tiles + scan_grid * WPB - 1) / (scan_grid * WPB));
+            TRY(ensure_worklist(c, scan_grid, seg));
+            ScanParams SP{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg};
+            hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
+            if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+            const uint32_t slow_grid = std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
+            c->blk_used = std::max(c->blk_used, slow_grid);
+            SlowParams SL{P, c->work, c->work_cnt, scan_grid, seg};
+            if (c->weighted)
+                hipLaunchKernelGGL(k_slow<true>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
+            else
+                hipLaunchKernelGGL(k_slow<false>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
+        }
+    } else if (ev) {
+        HIPCHK(c, hipEventRecord(ev->e1, c->stream));
     }
-    if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+    if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
     if (c->n_long) {
         LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, c->table, c->st};
         hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
@@ -667,6 +748,10 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     c->rec_n = 0;
     c->log_sites.clear();
     c->log_live.clear();
+    c->ev_iter.clear();
+    c->ev_us.clear();
+    c->ev_scan_us.clear();
+    c->split_mode = false;
     if (num_merges == 0) return YABPE_OK;
 
     if (c->rec_cap < num_merges) {
@@ -706,7 +791,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->n_partials = want_partials;
         }
         const uint32_t apply_grid = count_grid(c);
-        uint32_t batch_end = std::min(num_merges, i + check);
+        // sites per merge never increase (the best count is monotone): once they are sparse relative to the
+        // number of tiles, switch from the fused kernel to scan + balanced rewrite for good
+        const int64_t split_opt = optv(c, "split", -1);  // -1 auto, 0 never, 1 always
+        if (split_opt >= 0)
+            c->split_mode = split_opt == 1;
+        else if (!c->split_mode && h->iter > rec_base && h->best_count * 2 < c->n_tiles)
+            c->split_mode = true;
+        uint32_t batch_end = std::min(num_merges, i + ((i == 0 && !c->split_mode) ? std::min<uint32_t>(check, 8) : check));
         for (; i < batch_end; ++i) {
             EventPair *ev = nullptr;
             if (ev_sample && (i % ev_sample) == 0) {
@@ -714,6 +806,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                     EventPair n{};
                     HIPCHK(c, hipEventCreate(&n.e0));
                     HIPCHK(c, hipEventCreate(&n.e1));
+                    HIPCHK(c, hipEventCreate(&n.e2));
                     c->events.push_back(n);
                 }
                 c->events[ev_next].iter_rel = i;
@@ -745,7 +838,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             break;
         }
         // housekeeping between batches
-        if (h->table_entries * 4 > c->table_cap) TRY(table_rebuild(c, c->table_cap * 2));
+        if (h->table_entries * 2 > c->table_cap) TRY(table_grow(c, c->table_cap * 2));
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
             TRY(retile_flat(c));
@@ -786,10 +879,20 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         for (size_t e = 0; e < ev_next; ++e) {
             uint32_t k = c->events[e].iter_rel;
             if (k >= n) continue;
-            float ems = 0;
-            if (hipEventElapsedTime(&ems, c->events[e].e0, c->events[e].e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            float ems = 0, sms = 0;
+            if (hipEventElapsedTime(&ems, c->events[e].e0, c->events[e].e2) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (hipEventElapsedTime(&sms, c->events[e].e0, c->events[e].e1) != hipSuccess) { (void)hipGetLastError(); continue; }
             c->stats.apply_ms_sampled += ems;
+            c->ev_iter.push_back(k);
+            c->ev_us.push_back(ems * 1000.0f);
+            c->ev_scan_us.push_back(sms * 1000.0f);
             c->stats.apply_launches_sampled += 1;
+            if (c->events[e].split) {
+                c->stats.scan_ms_sampled += sms;
+                c->stats.scan_launches_sampled += 1;
+                c->stats.scan_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
+                c->stats.scan_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
+            }
             c->stats.apply_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
             c->stats.apply_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
         }
@@ -855,6 +958,15 @@ int yabpe_iter_log(yabpe_ctx *c, uint64_t *out_sites, uint64_t *out_live_slots, 
     if (out_sites) memcpy(out_sites, c->log_sites.data(), (size_t)n * 8);
     if (out_live_slots) memcpy(out_live_slots, c->log_live.data(), (size_t)n * 8);
     *out_n = (uint32_t)c->log_sites.size();
+    return YABPE_OK;
+}
+
+int yabpe_event_log(yabpe_ctx *c, uint32_t *out_iter, float *out_us, uint32_t cap, uint32_t *out_n) {
+    if (!c || !out_n) return YABPE_E_INVALID;
+    uint32_t n = std::min<uint32_t>(cap, (uint32_t)c->ev_iter.size());
+    if (out_iter) memcpy(out_iter, c->ev_iter.data(), (size_t)n * 4);
+    if (out_us) memcpy(out_us, c->ev_us.data(), (size_t)n * 4);
+    *out_n = (uint32_t)c->ev_iter.size();
     return YABPE_OK;
 }
 

@@ -52,6 +52,7 @@ struct DevState {
     unsigned long long sites;      // sites merged since the last k_select
     unsigned long long tokens_now; // T_i
     unsigned long long delta_entries;
+    unsigned long long best_count; // count of the merge being applied
 };
 
 struct PairTable {
@@ -377,39 +378,212 @@ __device__ __forceinline__ uint32_t bitmap_prefix(uint32_t word, int lane, uint3
     return inc - pc;
 }
 
+// What a workgroup needs to run the slow path
+template <class AggV>
+struct SlowCtx {
+    ApplyParams P;
+    Agg<AggV> agg;
+    DevState *st;
+    uint32_t a, b, c, mk, self;
+    int lane;
+};
+
+// Rewrites one tile that contains at least one candidate site: pair-count deltas, drop bitmap, compaction,
+// write-back.  Work is proportional to the number of sites.  Returns false when nothing changed.
+template <bool WEIGHTED, class AggV>
+__device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
+                                          uint32_t na, uint32_t nb, unsigned long long &wave_sites,
+                                          unsigned long long &wave_freed) {
+    const ApplyParams &P = C.P;
+    DevState *st = C.st;
+    const uint32_t a = C.a, b = C.b, c = C.c, mk = C.mk, self = C.self;
+    const int lane = C.lane;
+    uint16_t *stg = W.stage;
+    TokAt T{stg};
+    MrgBits M{W.mbits};
+    const int pA = lane * 8, pB = 512 + lane * 8; // first positions of this lane's two segments
+    wave_sync();
+    stage_tile(stg, r, lane);
+    uint32_t mA, mB; // site masks of the two segments
+    if (a != b) {
+        mA = match_mask8(r.va, na, mk);
+        mB = match_mask8(r.vb, nb, mk);
+    } else { // greedy parity rule over runs of a (trainer.py:276-285): through the round bitmaps
+        wave_sync();
+        const int rounds = (len + 63) >> 6;
+        const unsigned long long any = mark_sites(stg, W.mb, rounds, a, b, lane);
+        wave_sync();
+        if (!any) return false; // a lone candidate can lose to the parity rule -- never for a != b
+        mA = (pA >> 6) < rounds ? (uint32_t)(W.mb[1 + (pA >> 6)] >> (pA & 63)) & 0xffu : 0u;
+        mB = (pB >> 6) < rounds ? (uint32_t)(W.mb[1 + (pB >> 6)] >> (pB & 63)) & 0xffu : 0u;
+    }
+    // site bitmap (for M(p-2), M(p+2) lookups) and drop bitmap seeded with the PAD elements of the live prefix
+    reinterpret_cast<uint8_t *>(W.mbits + 1)[lane] = (uint8_t)mA;
+    reinterpret_cast<uint8_t *>(W.mbits + 1)[64 + lane] = (uint8_t)mB;
+    uint32_t dA = eq_mask8(r.va, YB_PAD), dB = eq_mask8(r.vb, YB_PAD);
+    if ((uint32_t)pA + 8 > len) dA &= (uint32_t)pA < len ? (1u << (len - pA)) - 1u : 0u;
+    if ((uint32_t)pB + 8 > len) dB &= (uint32_t)pB < len ? (1u << (len - pB)) - 1u : 0u;
+    reinterpret_cast<uint8_t *>(W.dmask)[lane] = (uint8_t)dA;
+    reinterpret_cast<uint8_t *>(W.dmask)[64 + lane] = (uint8_t)dB;
+    if (lane == 0) W.dmask[CAP / 32] = 0;
+    uint32_t wbase = 0;
+    if (WEIGHTED) {
+        reinterpret_cast<uint8_t *>(W.smask)[lane] = (uint8_t)eq_mask8(r.va, YB_SEP);
+        reinterpret_cast<uint8_t *>(W.smask)[64 + lane] = (uint8_t)eq_mask8(r.vb, YB_SEP);
+        wbase = P.tile_wbase[tile];
+    }
+    wave_sync();
+    if (WEIGHTED) {
+        uint32_t tot;
+        uint32_t pre = bitmap_prefix(lane < 32 ? W.smask[lane & 31] : 0u, lane, &tot);
+        if (lane < 32) W.spref[lane] = pre;
+        wave_sync();
+    }
+    // ---- deltas + drop marks: each lane walks its own sites (usually none or one)
+    uint32_t mm = mA | (mB << 8);
+    {
+        uint32_t tot = __popc(mm);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+        wave_sites += tot;
+    }
+    while (__any(mm != 0)) {
+        const bool site = mm != 0;
+        const int j = site ? (__ffs((int)mm) - 1) : 0;
+        mm &= mm - 1;
+        const int p = j < 8 ? pA + j : pB + (j - 8);
+        YbDeltas d;
+        d.left = d.right = false;
+        d.lo = d.ln = d.ro = d.rn = 0;
+        if (site) {
+            yb_site_deltas(p, a, b, c, T, M, d);
+            atomicOr(&W.dmask[(p + 1) >> 5], 1u << ((p + 1) & 31));
+            if (!WEIGHTED && yb_site_word_dies(p, T)) {
+                atomicOr(&W.dmask[p >> 5], 1u << (p & 31));
+                atomicOr(&W.dmask[(p + 2) >> 5], 1u << ((p + 2) & 31));
+            }
+        }
+        if constexpr (WEIGHTED) {
+            if (site) {
+                const uint32_t sw = W.smask[p >> 5];
+                const uint32_t widx = wbase + W.spref[p >> 5] + __popc(sw & ((1u << (p & 31)) - 1u));
+                const long long w = (long long)P.wfreq[widx];
+                if (d.left) {
+                    if (d.lo != self) agg_add(C.agg, P.out, st, d.lo, -w);
+                    agg_add(C.agg, P.out, st, d.ln, +w);
+                }
+                if (d.right) {
+                    if (d.ro != self) agg_add(C.agg, P.out, st, d.ro, -w);
+                    agg_add(C.agg, P.out, st, d.rn, +w);
+                }
+            }
+        } else {
+            agg_add_wave(C.agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane);
+            agg_add_wave(C.agg, P.out, st, d.left, d.ln, +1, lane);
+            agg_add_wave(C.agg, P.out, st, d.right && d.ro != self, d.ro, -1, lane);
+            agg_add_wave(C.agg, P.out, st, d.right, d.rn, +1, lane);
+        }
+    }
+    wave_sync();
+    // ---- compaction: every kept element moves left by the number of dropped elements before it
+    uint32_t dropped;
+    {
+        uint32_t pre = bitmap_prefix(lane < 32 ? W.dmask[lane & 31] : 0u, lane, &dropped);
+        if (lane < 32) W.dpref[lane] = pre;
+    }
+    wave_sync();
+    const uint32_t new_len = len - dropped;
+    uint32_t first_drop = CAP; // first changed position: 16-B groups before it are unchanged in HBM
+    {
+        const uint32_t dw = lane < 32 ? W.dmask[lane & 31] : 0u;
+        const unsigned long long nz = __ballot(dw != 0);
+        if (nz) {
+            const int wl = __ffsll((long long)nz) - 1;
+            first_drop = wl * 32 + (__ffs((int)__shfl(dw, wl)) - 1);
+        }
+        // a site at p rewrites slot p (a -> c) and drops p+1: the first CHANGED slot can be first_drop - 1
+        if (first_drop > 0) first_drop -= 1;
+    }
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const int p0 = seg ? pB : pA;
+        if ((uint32_t)p0 < len && (uint32_t)p0 + 8 > first_drop) {
+            const uint4 &v = seg ? r.vb : r.va;
+            const uint32_t sm = seg ? mB : mA;
+            const uint32_t dw = W.dmask[p0 >> 5];
+            uint32_t shift = W.dpref[p0 >> 5] + __popc(dw & ((1u << (p0 & 31)) - 1u));
+            const uint32_t db = (dw >> (p0 & 31)) & 0xffu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if ((db >> j) & 1u) {
+                    ++shift;
+                } else if ((uint32_t)(p0 + j) < len) {
+                    W.out[p0 + j - shift] = (uint16_t)(((sm >> j) & 1u) ? c : elem16(v, j));
+                }
+            }
+        }
+    }
+    const uint32_t pad_end = (new_len + 7u) & ~7u;
+    if (lane < 8 && new_len + lane < pad_end) W.out[new_len + lane] = YB_PAD;
+    wave_sync();
+    uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+    if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(W.out + pA);
+    if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(W.out + pB);
+    if (lane == 0) P.tile_len[tile] = new_len;
+    wave_freed += dropped;
+    return true;
+}
+
+__device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
+    if (lane < 8) {
+        W.stage[lane] = YB_PAD;
+        W.stage[8 + CAP + lane] = YB_PAD;
+    }
+    if (lane == 0) {
+        W.mbits[0] = 0;
+        W.mbits[1 + CAP / 32] = 0;
+    }
+}
+
+// per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
+template <class AggV>
+__device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> agg, DevState *st, unsigned long long *s_cnt,
+                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane) {
+    if (lane == 0) {
+        if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
+        if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // plain stores; k_select / k_fold_stats sum and clear them
+        P.blk_stats[2 * blockIdx.x] += s_cnt[0];
+        P.blk_stats[2 * blockIdx.x + 1] += s_cnt[1];
+    }
+    agg_flush(agg, P.out, st);
+}
+
+// ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
+// (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
 template <bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     __shared__ uint32_t s_keys[AGG_N];
     __shared__ AggV s_vals[AGG_N];
     __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
-
     __shared__ unsigned long long s_cnt[2];
 
     DevState *st = P.st;
     if (st->done | st->halt) return;
-    const uint32_t a = st->a, b = st->b, c = st->c;
-    const uint32_t mk = yb_memkey(a, b);
-    const uint32_t self = yb_pairkey(a, b); // its count was set to 0 by k_select: never updated here
-
-    Agg<AggV> agg{s_keys, s_vals};
-    agg_init(agg);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
+    const uint32_t mk = C.mk;
+    agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     WaveLds &W = s_w[wib];
-    uint16_t *stg = W.stage;
-    if (lane < 8) {
-        stg[lane] = YB_PAD;
-        stg[8 + CAP + lane] = YB_PAD;
-    }
-    if (lane == 0) {
-        W.mbits[0] = 0;
-        W.mbits[1 + CAP / 32] = 0;
-    }
+    wave_lds_init(W, lane);
     __syncthreads();
-    TokAt T{stg};
-    MrgBits M{W.mbits};
 
     unsigned long long wave_sites = 0; // wave-uniform
     unsigned long long wave_freed = 0; // slots removed from this wave's tiles
@@ -433,151 +607,143 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-
-            // ---- slow path: work proportional to the number of sites in this tile
-            const int pA = lane * 8, pB = 512 + lane * 8; // first positions of this lane's two segments
-            wave_sync();
-            stage_tile(stg, r, lane);
-            uint32_t mA, mB; // site masks of the two segments
-            if (a != b) {
-                mA = match_mask8(r.va, na, mk);
-                mB = match_mask8(r.vb, nb, mk);
-            } else { // greedy parity rule over runs of a (trainer.py:276-285): through the round bitmaps
-                wave_sync();
-                const int rounds = (len + 63) >> 6;
-                const unsigned long long any = mark_sites(stg, W.mb, rounds, a, b, lane);
-                wave_sync();
-                if (!any) continue;
-                mA = (pA >> 6) < rounds ? (uint32_t)(W.mb[1 + (pA >> 6)] >> (pA & 63)) & 0xffu : 0u;
-                mB = (pB >> 6) < rounds ? (uint32_t)(W.mb[1 + (pB >> 6)] >> (pB & 63)) & 0xffu : 0u;
-            }
-            // site bitmap (for M(p-2), M(p+2) lookups) and cleared drop bitmap
-            reinterpret_cast<uint8_t *>(W.mbits + 1)[lane] = (uint8_t)mA;
-            reinterpret_cast<uint8_t *>(W.mbits + 1)[64 + lane] = (uint8_t)mB;
-            // PAD elements inside the live prefix leave the tile as well
-            uint32_t dA = eq_mask8(r.va, YB_PAD), dB = eq_mask8(r.vb, YB_PAD);
-            if ((uint32_t)pA + 8 > len) dA &= (uint32_t)pA < len ? (1u << (len - pA)) - 1u : 0u;
-            if ((uint32_t)pB + 8 > len) dB &= (uint32_t)pB < len ? (1u << (len - pB)) - 1u : 0u;
-            reinterpret_cast<uint8_t *>(W.dmask)[lane] = (uint8_t)dA;
-            reinterpret_cast<uint8_t *>(W.dmask)[64 + lane] = (uint8_t)dB;
-            if (lane == 0) W.dmask[CAP / 32] = 0;
-            uint32_t wbase = 0;
-            if (WEIGHTED) {
-                reinterpret_cast<uint8_t *>(W.smask)[lane] = (uint8_t)eq_mask8(r.va, YB_SEP);
-                reinterpret_cast<uint8_t *>(W.smask)[64 + lane] = (uint8_t)eq_mask8(r.vb, YB_SEP);
-                wbase = P.tile_wbase[tile];
-            }
-            wave_sync();
-            if (WEIGHTED) {
-                uint32_t tot;
-                uint32_t pre = bitmap_prefix(lane < 32 ? W.smask[lane & 31] : 0u, lane, &tot);
-                if (lane < 32) W.spref[lane] = pre;
-                wave_sync();
-            }
-            // ---- deltas + drop marks: each lane walks its own sites (usually none or one)
-            uint32_t mm = mA | (mB << 8);
-            {
-                uint32_t tot = __popc(mm);
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
-                wave_sites += tot;
-            }
-            while (__any(mm != 0)) {
-                const bool site = mm != 0;
-                const int j = site ? (__ffs((int)mm) - 1) : 0;
-                mm &= mm - 1;
-                const int p = j < 8 ? pA + j : pB + (j - 8);
-                YbDeltas d;
-                d.left = d.right = false;
-                d.lo = d.ln = d.ro = d.rn = 0;
-                if (site) {
-                    yb_site_deltas(p, a, b, c, T, M, d);
-                    atomicOr(&W.dmask[(p + 1) >> 5], 1u << ((p + 1) & 31));
-                    if (!WEIGHTED && yb_site_word_dies(p, T)) {
-                        atomicOr(&W.dmask[p >> 5], 1u << (p & 31));
-                        atomicOr(&W.dmask[(p + 2) >> 5], 1u << ((p + 2) & 31));
-                    }
-                }
-                if constexpr (WEIGHTED) {
-                    if (site) {
-                        const uint32_t sw = W.smask[p >> 5];
-                        const uint32_t widx = wbase + W.spref[p >> 5] + __popc(sw & ((1u << (p & 31)) - 1u));
-                        const long long w = (long long)P.wfreq[widx];
-                        if (d.left) {
-                            if (d.lo != self) agg_add(agg, P.out, st, d.lo, -w);
-                            agg_add(agg, P.out, st, d.ln, +w);
-                        }
-                        if (d.right) {
-                            if (d.ro != self) agg_add(agg, P.out, st, d.ro, -w);
-                            agg_add(agg, P.out, st, d.rn, +w);
-                        }
-                    }
-                } else {
-                    agg_add_wave(agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane);
-                    agg_add_wave(agg, P.out, st, d.left, d.ln, +1, lane);
-                    agg_add_wave(agg, P.out, st, d.right && d.ro != self, d.ro, -1, lane);
-                    agg_add_wave(agg, P.out, st, d.right, d.rn, +1, lane);
-                }
-            }
-            wave_sync();
-            // ---- compaction: every kept element moves left by the number of dropped elements before it
-            uint32_t dropped;
-            {
-                uint32_t pre = bitmap_prefix(lane < 32 ? W.dmask[lane & 31] : 0u, lane, &dropped);
-                if (lane < 32) W.dpref[lane] = pre;
-            }
-            wave_sync();
-            const uint32_t new_len = len - dropped;
-            uint32_t first_drop = CAP; // first changed position: 16-B groups before it are unchanged in HBM
-            {
-                const uint32_t dw = lane < 32 ? W.dmask[lane & 31] : 0u;
-                const unsigned long long nz = __ballot(dw != 0);
-                if (nz) {
-                    const int wl = __ffsll((long long)nz) - 1;
-                    first_drop = wl * 32 + (__ffs((int)__shfl(dw, wl)) - 1);
-                }
-                // a site at p rewrites slot p (a -> c) and drops p+1: the first CHANGED slot can be first_drop - 1
-                if (first_drop > 0) first_drop -= 1;
-            }
-#pragma unroll
-            for (int seg = 0; seg < 2; ++seg) {
-                const int p0 = seg ? pB : pA;
-                if ((uint32_t)p0 < len && (uint32_t)p0 + 8 > first_drop) {
-                    const uint4 &v = seg ? r.vb : r.va;
-                    const uint32_t sm = seg ? mB : mA;
-                    const uint32_t dw = W.dmask[p0 >> 5];
-                    uint32_t shift = W.dpref[p0 >> 5] + __popc(dw & ((1u << (p0 & 31)) - 1u));
-                    const uint32_t db = (dw >> (p0 & 31)) & 0xffu;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if ((db >> j) & 1u) {
-                            ++shift;
-                        } else if ((uint32_t)(p0 + j) < len) {
-                            W.out[p0 + j - shift] = (uint16_t)(((sm >> j) & 1u) ? c : elem16(v, j));
-                        }
-                    }
-                }
-            }
-            const uint32_t pad_end = (new_len + 7u) & ~7u;
-            if (lane < 8 && new_len + lane < pad_end) W.out[new_len + lane] = YB_PAD;
-            wave_sync();
-            uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-            if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(W.out + pA);
-            if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(W.out + pB);
-            if (lane == 0) P.tile_len[tile] = new_len;
-            wave_freed += dropped;
+            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
         }
     }
-    if (lane == 0) {
-        if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
-        if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+}
+
+// ---------------------------------------------------------------- split form, pass 1: pure streaming scan
+// Reads the live token stream once (the roofline pass) and records which tiles contain the pair.  No LDS
+// tables, few registers; every workgroup appends to its own segment of the worklist: no global atomics.
+struct ScanParams {
+    const uint16_t *tiles;
+    const uint32_t *tile_len;
+    uint32_t n_tiles;
+    DevState *st;
+    uint32_t *work;     // [gridDim.x * seg] tile ids
+    uint32_t *work_cnt; // [gridDim.x]
+    uint32_t seg;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
+    __shared__ uint32_t s_n;
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    const uint32_t mk = yb_memkey(st->a, st->b);
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t *my_work = P.work + (size_t)blockIdx.x * P.seg;
+    const uint32_t stride = gridDim.x * WPB;
+    const uint32_t n_tiles = P.n_tiles;
+    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
+        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
+        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
+        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
+        TileRegs q0 = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
+        TileRegs q1 = q0;
+        if (cnt > 1) q1 = load_tile(P.tiles, batch + stride, __builtin_amdgcn_readlane(my_len, 1), lane);
+        for (uint32_t i = 0; i < cnt; ++i) { // two tiles in flight per wave
+            const uint32_t tile = batch + i * stride;
+            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
+            const TileRegs r = q0;
+            q0 = q1;
+            if (i + 2 < cnt) q1 = load_tile(P.tiles, tile + 2 * stride, __builtin_amdgcn_readlane(my_len, i + 2), lane);
+            if (len == 0) continue;
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            if (lane == 0) my_work[atomicAdd(&s_n, 1u)] = tile;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // plain stores; k_select / k_fold_stats sum and clear them
-        P.blk_stats[2 * blockIdx.x] = s_cnt[0];
-        P.blk_stats[2 * blockIdx.x + 1] = s_cnt[1];
+    if (threadIdx.x == 0) P.work_cnt[blockIdx.x] = s_n;
+}
+
+// ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
+struct SlowParams {
+    ApplyParams A;
+    const uint32_t *work;
+    const uint32_t *work_cnt;
+    uint32_t n_lists; // grid of k_scan
+    uint32_t seg;
+};
+constexpr int MAX_LISTS = 2048;
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
+    __shared__ unsigned long long s_cnt[2];
+    __shared__ uint32_t s_pref[MAX_LISTS + 1];
+    __shared__ uint32_t s_wsum[WPB];
+
+    const ApplyParams &P = S.A;
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // exclusive prefix over the per-workgroup list lengths (every workgroup computes the same small scan)
+    constexpr int PER = MAX_LISTS / BLOCK;
+    uint32_t v[PER], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = threadIdx.x * PER + k;
+        v[k] = i < S.n_lists ? S.work_cnt[i] : 0u;
+        tsum += v[k];
     }
-    agg_flush(agg, P.out, st);
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_wsum[wib] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wib; ++w) woff += s_wsum[w];
+    uint32_t run = woff + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        s_pref[threadIdx.x * PER + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == BLOCK - 1) s_pref[MAX_LISTS] = run;
+    __syncthreads();
+    const uint32_t total = s_pref[MAX_LISTS];
+    if (blockIdx.x * WPB >= total) return; // nothing for this workgroup (uniform)
+
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b);
+    agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    WaveLds &W = s_w[wib];
+    wave_lds_init(W, lane);
+    __syncthreads();
+    unsigned long long wave_sites = 0, wave_freed = 0;
+    const uint32_t n_waves = gridDim.x * WPB;
+    for (uint32_t g = blockIdx.x * WPB + wib; g < total; g += n_waves) {
+        // list that holds item g: last l with s_pref[l] <= g
+        uint32_t lo = 0, hi = S.n_lists;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t tile = S.work[(size_t)lo * S.seg + (g - s_pref[lo])];
+        const uint32_t len = P.tile_len[tile];
+        const TileRegs r = load_tile(P.tiles, tile, len, lane);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+        const uint32_t na = next_lane(r.va.x, b0);
+        const uint32_t nb = next_lane(r.vb.x, PADPAD);
+        slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+    }
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
 }
 
 // ================================================================ long words (> LMAX-1 tokens): one workgroup per word
@@ -934,6 +1100,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         st->a = x;
         st->b = y;
         st->c = cid;
+        st->best_count = s_b[0].cnt;
         st->c_is_new = is_new;
         st->iter = it + 1;
     }
@@ -1068,6 +1235,21 @@ __global__ __launch_bounds__(BLOCK) void k_sum_u32(const uint32_t *p, unsigned l
     for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) s += p[i];
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// ================================================================ table growth: re-insert live entries (count != 0)
+struct RehashParams {
+    PairTable from, to;
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_rehash(RehashParams P) {
+    const uint32_t cap = P.from.mask + 1;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
+        const uint32_t k = P.from.keys[s];
+        if (k == EMPTY) continue;
+        const long long v = (long long)P.from.cnt[s];
+        if (v != 0) gt_add(P.to, P.st, k, v);
+    }
 }
 
 // ================================================================ debug: compare two pair tables

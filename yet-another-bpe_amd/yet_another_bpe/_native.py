@@ -26,7 +26,9 @@ class Stats(ctypes.Structure):
         "n_words", "n_words_input", "n_long_words", "tokens_initial", "tokens_now", "merges_done", "n_tiles",
         "live_slots", "table_capacity", "table_entries", "retiles", "table_rebuilds")] + [
         ("load_ms", c_double), ("train_ms", c_double), ("apply_ms_sampled", c_double)] + [(n, c_uint64) for n in (
-            "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")]
+            "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")] + [
+        ("scan_ms_sampled", c_double)] + [(n, c_uint64) for n in (
+            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled")]
 
 
 _lib = None
@@ -35,7 +37,7 @@ _lib = None
 SYMBOLS = [
     "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
-    "yabpe_iter_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
+    "yabpe_iter_log", "yabpe_event_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
     "yabpe_memcpy_d2h", "yabpe_comm_unique_id", "yabpe_comm_init",
 ]
 
@@ -63,6 +65,7 @@ def lib() -> ctypes.CDLL:
         L.yabpe_token_bytes.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_uint32)]
         L.yabpe_stats.argtypes = [c_void_p, POINTER(Stats)]
         L.yabpe_iter_log.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
+        L.yabpe_event_log.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
         L.yabpe_verify_table.argtypes = [c_void_p, POINTER(c_uint64)]
         L.yabpe_stream_checksum.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_generate.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32, c_int,
@@ -183,6 +186,14 @@ class Context:
         live = np.zeros(max(n.value, 1), dtype=np.uint64)
         self._chk(lib().yabpe_iter_log(self._h, sites.ctypes.data, live.ctypes.data, n.value, byref(n)))
         return sites[:n.value], live[:n.value]
+
+    def event_log(self):
+        n = c_uint32(0)
+        self._chk(lib().yabpe_event_log(self._h, None, None, 0, byref(n)))
+        it = np.zeros(max(n.value, 1), dtype=np.uint32)
+        us = np.zeros(max(n.value, 1), dtype=np.float32)
+        self._chk(lib().yabpe_event_log(self._h, it.ctypes.data, us.ctypes.data, n.value, byref(n)))
+        return it[:n.value], us[:n.value]
 
     def verify_table(self) -> int:
         m = c_uint64(0)
