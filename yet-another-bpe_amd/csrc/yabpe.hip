@@ -87,7 +87,8 @@ struct yabpe_ctx {
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
     uint32_t blk_used = 0;                    // largest grid that wrote blk_stats
     // split apply: worklist of tiles that contain the pair
-    uint32_t *work = nullptr, *work_cnt = nullptr;
+    uint2 *work = nullptr;
+    uint32_t *work_cnt = nullptr;
     uint64_t work_cap = 0;
     bool split_mode = false;
     std::vector<float> ev_scan_us;

@@ -621,7 +621,7 @@ struct ScanParams {
     const uint32_t *tile_len;
     uint32_t n_tiles;
     DevState *st;
-    uint32_t *work;     // [gridDim.x * seg] tile ids
+    uint2 *work;        // [gridDim.x * seg] (tile id, live length)
     uint32_t *work_cnt; // [gridDim.x]
     uint32_t seg;
 };
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    uint32_t *my_work = P.work + (size_t)blockIdx.x * P.seg;
+    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     const uint32_t stride = gridDim.x * WPB;
     const uint32_t n_tiles = P.n_tiles;
     for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            if (lane == 0) my_work[atomicAdd(&s_n, 1u)] = tile;
+            if (lane == 0) my_work[atomicAdd(&s_n, 1u)] = make_uint2(tile, len);
         }
     }
     __syncthreads();
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
 // ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
 struct SlowParams {
     ApplyParams A;
-    const uint32_t *work;
+    const uint2 *work;
     const uint32_t *work_cnt;
     uint32_t n_lists; // grid of k_scan
     uint32_t seg;
@@ -728,16 +728,27 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     __syncthreads();
     unsigned long long wave_sites = 0, wave_freed = 0;
     const uint32_t n_waves = gridDim.x * WPB;
-    for (uint32_t g = blockIdx.x * WPB + wib; g < total; g += n_waves) {
-        // list that holds item g: last l with s_pref[l] <= g
+    // item g -> (tile, len): find the list that holds it (last l with s_pref[l] <= g)
+    auto fetch = [&](uint32_t g) -> uint2 {
         uint32_t lo = 0, hi = S.n_lists;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (s_pref[mid] <= g) lo = mid; else hi = mid;
         }
-        const uint32_t tile = S.work[(size_t)lo * S.seg + (g - s_pref[lo])];
-        const uint32_t len = P.tile_len[tile];
-        const TileRegs r = load_tile(P.tiles, tile, len, lane);
+        return S.work[(size_t)lo * S.seg + (g - s_pref[lo])];
+    };
+    uint32_t g = blockIdx.x * WPB + wib;
+    uint2 item = make_uint2(0u, 0u);
+    if (g < total) item = fetch(g); // (a wave past the end must not index the worklist at all)
+    TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
+    while (g < total) { // the next item's descriptor and data are in flight while this one is rewritten
+        const uint32_t tile = item.x, len = item.y;
+        const TileRegs r = nxt;
+        g += n_waves;
+        if (g < total) {
+            item = fetch(g);
+            nxt = load_tile(P.tiles, item.x, item.y, lane);
+        }
         const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
         const uint32_t na = next_lane(r.va.x, b0);
         const uint32_t nb = next_lane(r.vb.x, PADPAD);
