@@ -210,8 +210,21 @@ int fold_stats(yabpe_ctx *c) {
 }
 
 // full recount of the resident stream into `t` (zeroed by the caller)
-int launch_count(yabpe_ctx *c, PairTable t) {
-    if (c->n_tiles) {
+int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
+    if (c->n_tiles && all_bytes && !c->weighted && optv(c, "dense_count", 1)) {
+        // initial count of the flat layout: every token is still a byte (trainer.py:227-235 over 256 x 256 keys)
+        unsigned long long *dense = nullptr;
+        TRY(dmalloc(c, &dense, 65536));
+        HIPCHK(c, hipMemsetAsync(dense, 0, 65536 * 8, c->stream));
+        const uint32_t bpp = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(c->n_cu / 2, (c->n_tiles + CB_WAVES - 1) / CB_WAVES));
+        CountBytesParams P{c->tiles, c->tile_len, c->n_tiles, dense, bpp};
+        hipLaunchKernelGGL(k_count_bytes, dim3(4 * bpp), dim3(CB_BLOCK), 0, c->stream, P);
+        DenseToTableParams D{dense, t, c->st};
+        hipLaunchKernelGGL(k_dense_to_table, dim3(65536 / BLOCK), dim3(BLOCK), 0, c->stream, D);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(dense);
+    } else if (c->n_tiles) {
         CountParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, t, c->st};
         if (c->weighted)
             hipLaunchKernelGGL(k_count<true>, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
@@ -228,7 +241,7 @@ int launch_count(yabpe_ctx *c, PairTable t) {
 }
 
 // (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
-int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
+int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
     for (int attempt = 0; attempt < 16; ++attempt) {
         table_free(c->table);
@@ -236,7 +249,7 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap) {
         HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, sizeof(uint32_t), c->stream));
         TRY(table_alloc(c, c->table, cap, &c->st->table_entries));
         c->table_cap = cap;
-        TRY(launch_count(c, c->table));
+        TRY(launch_count(c, c->table, all_bytes));
         TRY(state_pull(c));
         if (c->st_host->halt_req == 0 && c->st_host->table_entries * 2 <= cap) {
             c->stats.table_rebuilds++;
@@ -638,7 +651,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     h->table_entries = 0;
     TRY(state_push(c));
     TRY(refresh_live_slots(c));
-    TRY(table_rebuild(c, 0));
+    TRY(table_rebuild(c, 1ull << 18, /*all_bytes=*/true));  // 65,536 possible byte pairs: start at load <= 1/4
     c->stats.table_rebuilds = 0;
     HIPCHK(c, hipEventRecord(ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(ev1));

@@ -378,6 +378,67 @@ __device__ __forceinline__ uint32_t bitmap_prefix(uint32_t word, int lane, uint3
     return inc - pc;
 }
 
+// ================================================================ k_count_bytes: initial count of the flat layout
+// At load time every token is a byte, so the key space is exactly 256 x 256.  Four passes, pass q owning the
+// pairs whose left byte is in [64q, 64q+64): a 64 KiB dense u32 histogram per workgroup in LDS (no hashing, no
+// HBM atomics in the loop), flushed into a dense u64 array, which k_dense_to_table then inserts into the table.
+constexpr int CB_BLOCK = 1024;
+constexpr int CB_WAVES = CB_BLOCK / 64;
+struct CountBytesParams {
+    const uint16_t *tiles;
+    const uint32_t *tile_len;
+    uint32_t n_tiles;
+    unsigned long long *dense; // [65536]
+    uint32_t blocks_per_pass;
+};
+
+__global__ __launch_bounds__(CB_BLOCK) void k_count_bytes(CountBytesParams P) {
+    __shared__ uint32_t s_hist[64 * 256];
+    const uint32_t pass = blockIdx.x / P.blocks_per_pass;
+    const uint32_t bip = blockIdx.x % P.blocks_per_pass;
+    for (int i = threadIdx.x; i < 64 * 256; i += CB_BLOCK) s_hist[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t stride = P.blocks_per_pass * CB_WAVES;
+    for (uint32_t tile = bip * CB_WAVES + wib; tile < P.n_tiles; tile += stride) {
+        const uint32_t len = P.tile_len[tile];
+        if (len == 0) continue;
+        const TileRegs r = load_tile(P.tiles, tile, len, lane);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+        const uint32_t na = next_lane(r.va.x, b0);
+        const uint32_t nb = next_lane(r.vb.x, PADPAD);
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            const uint4 &v = seg ? r.vb : r.va;
+            const uint32_t nx = (seg ? nb : na) & 0xffffu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t x = elem16(v, j);
+                const uint32_t y = j < 7 ? elem16(v, j + 1) : nx;
+                if ((x >> 6) == pass && y < 256u) atomicAdd(&s_hist[((x & 63u) << 8) | y], 1u); // x < 256 implied
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 256; i += CB_BLOCK) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&P.dense[pass * 16384u + i], (unsigned long long)v);
+    }
+}
+
+struct DenseToTableParams {
+    const unsigned long long *dense;
+    PairTable table;
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_dense_to_table(DenseToTableParams P) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x; // i = left * 256 + right
+    if (i >= 65536u) return;
+    const unsigned long long v = P.dense[i];
+    if (v) gt_add(P.table, P.st, yb_pairkey(i >> 8, i & 255u), (long long)v);
+}
+
 // What a workgroup needs to run the slow path
 template <class AggV>
 struct SlowCtx {
@@ -890,10 +951,10 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_partial(ArgmaxParams P) {
     Best best{0ull, 0u, EMPTY, 0u, 0u};
     const uint32_t cap = P.table.mask + 1;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
-        uint32_t k = P.table.keys[s];
-        if (k == EMPTY) continue;
-        long long cn = (long long)P.table.cnt[s];
+        const long long cn = (long long)P.table.cnt[s]; // empty slots hold 0: the key is read for candidates only
         if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
+        const uint32_t k = P.table.keys[s];
+        if (k == EMPTY) continue;
         Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
         if (best_gt(e, best)) best = e;
     }
