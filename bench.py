@@ -97,6 +97,7 @@ def main() -> None:
         from yet_another_bpe import distributed as ydist
 
         runner = ydist.ShardedRunner(gen, pb, po, n_words, n_bytes, base, rank, world, local_rank)
+        runner._context()  # rendezvous + RCCL communicator before the timed region
     else:
         runner = None
 
@@ -189,6 +190,8 @@ def main() -> None:
     if rank == 0 and not args.no_cpu_baseline:
         cb, (cflat, coff, cmg) = cpu_baseline(gen, pb, po, n_words, n_bytes, args.merges, args.cpu_sample_mib << 20, specials)
         out["cpu_baseline"] = cb
+    if runner is not None:
+        runner.close()
     gen.close()
     if dist is not None:
         dist.barrier()

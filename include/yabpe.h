@@ -133,13 +133,23 @@ int yabpe_synth_generate(yabpe_ctx *ctx, uint64_t target_bytes, uint32_t n_types
 int yabpe_synth_free(yabpe_ctx *ctx);
 /* Copy `n` bytes device->host / host->device (for fixtures and the CPU-baseline sample). */
 int yabpe_memcpy_d2h(yabpe_ctx *ctx, void *dst_host, const void *src_dev, uint64_t n);
+int yabpe_memcpy_h2d(yabpe_ctx *ctx, void *dst_dev, const void *src_host, uint64_t n);
 
 /* Multi-GPU (one process per GPU; words are sharded by the caller) -----------------
  * Every rank holds its shard of the words and a replica of the pair table.  After each apply pass the ranks
- * exchange their aggregated (pair, delta) records with one RCCL all-gather and apply all of them.
- * unique_id: the 128-byte ncclUniqueId produced by yabpe_comm_unique_id on rank 0 and broadcast by the caller. */
+ * exchange their aggregated (pair, delta) records with ONE all-gather on the compute stream and every rank adds all
+ * of them to its replica (integer sums: order-independent, so all ranks select the same merge).
+ * Attach the communicator after yabpe_create / yabpe_set_vocab and BEFORE yabpe_load_words; then every rank calls
+ * yabpe_load_words (its shard: word_off may point into the middle of a larger offsets array) and yabpe_train
+ * collectively with the same arguments.  All ranks return the same merges.
+ * unique_id: the 128-byte ncclUniqueId made by yabpe_comm_unique_id on rank 0 and broadcast by the caller. */
 int yabpe_comm_unique_id(uint8_t out_id[128]);
 int yabpe_comm_init(yabpe_ctx *ctx, int rank, int n_ranks, const uint8_t unique_id[128]);
+/* Same protocol over a caller-supplied transport instead of RCCL (other fabrics; the repo's tests use it to run
+ * 2 ranks on one GPU).  fn must gather `nbytes` from every rank's DEVICE buffer send_dev into recv_dev (rank
+ * order) and return 0; it is called with the context's stream idle. */
+typedef int (*yabpe_allgather_fn)(void *user, const void *send_dev, void *recv_dev, uint64_t nbytes);
+int yabpe_comm_init_custom(yabpe_ctx *ctx, int rank, int n_ranks, yabpe_allgather_fn fn, void *user);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,193 @@
+"""Worker functions for the multi-rank tests (spawned with torch.multiprocessing, gloo on 127.0.0.1)."""
+from __future__ import annotations
+
+import os
+import sys
+import traceback
+from collections import Counter
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+for p in (REPO, REPO / "yet-another-bpe_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+
+def _init(rank: int, world: int, port: int):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _run(fn, rank, world, port, q, *args):
+    try:
+        dist = _init(rank, world, port)
+        out = fn(rank, world, dist, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", out))
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def spawn(fn, world: int, *args, timeout: float = 600.0):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, status, out = q.get(timeout=timeout)
+            assert status == "ok", f"rank {rank} failed:\n{out}"
+            results[rank] = out
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return [results[r] for r in range(world)]
+
+
+# ---------------------------------------------------------------- CPU: transport plumbing + the distributed algorithm
+def cpu_transport_roundtrip(rank, world, dist):
+    """The yabpe_allgather_fn callback path with host memory standing in for device memory."""
+    import ctypes
+
+    import numpy as np
+
+    from yet_another_bpe import _native
+    from yet_another_bpe.distributed import host_memory_transport
+
+    n = 1000
+    send = np.full(n, rank + 1, dtype=np.uint8)
+    send[0] = 7 * rank
+    recv = np.zeros(n * world, dtype=np.uint8)
+    tr = host_memory_transport()
+    cb = _native.ALLGATHER_FN(lambda _u, s, r, nb: tr(s, r, nb))  # exactly how Context.comm_init_custom wraps it
+    rc = cb(None, ctypes.c_void_p(send.ctypes.data), ctypes.c_void_p(recv.ctypes.data), n)
+    assert rc == 0
+    for r in range(world):
+        assert recv[r * n] == 7 * r and (recv[r * n + 1:(r + 1) * n] == r + 1).all()
+    return int(recv.sum())
+
+
+def cpu_sharded_reference(rank, world, dist, words_hex, specials, vocab_size, min_frequency):
+    """Pure-Python model of the multi-GPU protocol: word shards, replicated pair table, per-merge exchange of
+    aggregated (pair, delta) records, identical argmax on every rank.  Returns the merges as hex pairs."""
+    import numpy as np
+
+    from yet_another_bpe.distributed import plan_shards
+
+    words = [bytes.fromhex(w) for w in words_hex]
+    lens = np.array([len(w) for w in words], dtype=np.uint64)
+    off = np.zeros(len(words) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    w0, w1 = plan_shards(off, world)[rank]
+    mine = [tuple(bytes([b]) for b in w) for w in words[w0:w1]]
+    vocab = {bytes([b]): b for b in range(256)}
+    for s in specials:
+        if s.encode() not in vocab:
+            vocab[s.encode()] = len(vocab)
+
+    def local_counts(ws):
+        c = Counter()
+        for w in ws:
+            for j in range(len(w) - 1):
+                c[(w[j], w[j + 1])] += 1
+        return c
+
+    def exchange(delta: dict):
+        parts = [None] * world
+        dist.all_gather_object(parts, sorted(delta.items()))
+        return parts
+
+    table = Counter()
+    for part in exchange(local_counts(mine)):  # initial count: sum of the shards' histograms
+        for k, v in part:
+            table[k] += v
+    merges = []
+    for _ in range(max(0, vocab_size - len(vocab))):
+        live = {k: v for k, v in table.items() if v > 0}
+        if not live:
+            break
+        best = max(live.items(), key=lambda kv: (kv[1], kv[0]))[0]
+        if live[best] < min_frequency:
+            break
+        x, y = best
+        z = x + y
+        before = local_counts(mine)
+        new = []
+        for w in mine:
+            out, j = [], 0
+            while j < len(w):
+                if j + 1 < len(w) and w[j] == x and w[j + 1] == y:
+                    out.append(z)
+                    j += 2
+                else:
+                    out.append(w[j])
+                    j += 1
+            new.append(tuple(out))
+        mine = new
+        after = local_counts(mine)
+        delta = {k: after.get(k, 0) - before.get(k, 0) for k in set(before) | set(after)}
+        delta = {k: v for k, v in delta.items() if v != 0 and k != best}  # the merged pair is zeroed, not updated
+        table[best] = 0
+        for part in exchange(delta):
+            for k, v in part:
+                table[k] += v
+        merges.append(best)
+        if z not in vocab:
+            vocab[z] = len(vocab)
+    return [(a.hex(), b.hex()) for a, b in merges], len(vocab)
+
+
+# ---------------------------------------------------------------- GPU: 2 ranks on one GPU through the custom transport
+def gpu_sharded(rank, world, dist, scenario):
+    import numpy as np
+
+    from tests import helpers
+    from yet_another_bpe import _native, synth
+    from yet_another_bpe.distributed import train_sharded
+
+    sp = ["<|endoftext|>"]
+    base = helpers.base_tokens(sp)
+    opts = {"verify": 1}
+    if scenario == "corpus_en_flat":
+        flat, off = helpers.flatten(helpers.corpus_en_words())
+        freq, merges = None, 700
+    elif scenario == "corpus_en_weighted":
+        uw, fq = helpers.pooled(helpers.corpus_en_words())
+        flat, off = helpers.flatten(uw)
+        freq, merges = fq, 700
+    elif scenario == "synthetic_small_buffers":  # forces DELTA_FULL / TABLE_FULL recoveries and retiles
+        flat, off = synth.generate(synth.SynthSpec(3 << 20, 20_000, 9, bytes(range(256)), False))
+        freq, merges = None, 400
+        opts.update({"delta_cap": 4, "delta_table_log2": 6, "table_min_log2": 10, "check_interval": 5,
+                     "retile_pct": 95, "retile_min_tiles": 8})
+    elif scenario == "long_words":
+        words = [b" " * 900, b"ab" * 700, b"xyz" * 50, b"abcabc", b"  ", b"aaa"] * 3 + [b"hello world"] * 5
+        flat, off = helpers.flatten(words)
+        freq, merges = None, 120
+    else:
+        raise ValueError(scenario)
+    left, right, merged, count, stats = train_sharded(lambda: _native.Context(0), flat, off, freq, base, merges, 1, rank, world,
+                                                      transport="torch", options=opts)
+    toks = list(base)
+    out = []
+    for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+        out.append((toks[l].hex(), toks[r].hex()))
+        if m == len(toks):
+            toks.append(toks[l] + toks[r])
+    return out, int(stats["n_words"]), int(stats["table_rebuilds"]), int(stats["retiles"])

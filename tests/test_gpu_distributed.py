@@ -1,0 +1,63 @@
+"""GPU (-m gpu): the multi-rank path of libyabpe.so with TWO ranks sharing the one GPU of the test box.
+RCCL refuses two ranks on one device, so the ranks exchange through the custom transport (yabpe_comm_init_custom,
+gloo underneath); everything else -- sharded load, per-rank delta tables, extract / all-gather / apply kernels,
+in-band halts, global recounts -- is the code the RCCL transport runs too.  Merges must equal the oracle's."""
+from __future__ import annotations
+
+import pytest
+
+from oracle import oracle
+from tests import dist_workers, helpers
+
+pytestmark = pytest.mark.gpu
+SP = ["<|endoftext|>"]
+
+
+def _expect(scenario):
+    from yet_another_bpe import synth
+
+    if scenario.startswith("corpus_en"):
+        return oracle.merge_loop(helpers.corpus_en_words(), 257 + 700, 1, SP)[1]
+    if scenario == "synthetic_small_buffers":
+        flat, off = synth.generate(synth.SynthSpec(3 << 20, 20_000, 9, bytes(range(256)), False))
+        return oracle.train_flat(flat, off, 257 + 400, 1, SP)[1]
+    words = [b" " * 900, b"ab" * 700, b"xyz" * 50, b"abcabc", b"  ", b"aaa"] * 3 + [b"hello world"] * 5
+    return oracle.merge_loop(words, 257 + 120, 1, SP)[1]
+
+
+@pytest.mark.parametrize("scenario", ["corpus_en_flat", "corpus_en_weighted", "synthetic_small_buffers", "long_words"])
+def test_two_ranks_one_gpu(scenario):
+    exp = _expect(scenario)
+    outs = dist_workers.spawn(dist_workers.gpu_sharded, 2, scenario, timeout=900)
+    for merges, n_words, rebuilds, retiles in outs:
+        assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp
+    assert outs[0][1] > 0 and outs[1][1] > 0  # both ranks held words
+    if scenario == "synthetic_small_buffers":
+        assert outs[0][2] >= 1  # the overflow recovery (global recount) ran
+
+
+def test_rccl_transport_single_rank_smoke():
+    """The real RCCL calls (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the compute stream) with a
+    1-rank communicator: the exchange path runs end to end through librccl and must not change the result."""
+    from yet_another_bpe import _native
+
+    words = helpers.corpus_en_words()
+    base = helpers.base_tokens(SP)
+    flat, off = helpers.flatten(words)
+    exp = oracle.merge_loop(words, 257 + 300, 1, SP)[1]
+    with _native.Context(0) as ctx:
+        ctx.set_option("force_comm", 1)
+        ctx.set_option("verify", 1)
+        ctx.set_vocab(base)
+        uid = _native.Context.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        ctx.comm_init(0, 1, uid)
+        ctx.load_words(flat, off)
+        left, right, merged, _ = ctx.train(300, 1)
+    toks = list(base)
+    got = []
+    for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+        got.append((toks[l], toks[r]))
+        if m == len(toks):
+            toks.append(toks[l] + toks[r])
+    assert got == exp

@@ -7,6 +7,8 @@
 // in HBM.  The host looks at DevState every `check_interval` merges to stop early (done), to service a
 // halt (grow + recount the pair table) and to retile the shrinking token stream.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed when yabpe_comm_* is first used
 
 #include <algorithm>
 #include <cstdarg>
@@ -23,6 +25,37 @@
 using namespace yb;
 
 namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (r.h) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+            r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.AllReduce || !r.CommDestroy) r.h = nullptr;
+        }
+    }
+    return r.h ? &r : nullptr;
+}
 
 constexpr uint32_t MAX_APPLY_BLOCKS = 8192;
 thread_local std::string g_create_error;
@@ -83,7 +116,8 @@ struct yabpe_ctx {
     // synth buffers
     std::vector<void *> synth_bufs;
     // misc device scratch
-    unsigned long long *scratch64 = nullptr;  // 8 x u64
+    unsigned long long *scratch64 = nullptr;  // 16 x u64: [0] live sum [1] freq overflow [2,3] long words [4,5,6] verify/checksum
+                                              // [7] comm_max [8] exchange record count [9] local count-table entries
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
     uint32_t blk_used = 0;                    // largest grid that wrote blk_stats
     // split apply: worklist of tiles that contain the pair
@@ -92,6 +126,18 @@ struct yabpe_ctx {
     uint64_t work_cap = 0;
     bool split_mode = false;
     std::vector<float> ev_scan_us;
+    // multi-GPU
+    int rank = 0, n_ranks = 1;
+    bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
+    ncclComm_t comm = nullptr;
+    yabpe_allgather_fn ag_fn = nullptr;  // custom transport (tests / other fabrics) instead of RCCL
+    void *ag_user = nullptr;
+    unsigned long long *xsmall = nullptr;  // n_ranks x u64 receive slots for small agreements
+    PairTable delta{};      // per-rank delta table (apply passes add here instead of into `table`)
+    uint8_t *xsend = nullptr, *xrecv = nullptr;
+    uint32_t xcap = 0;      // records per rank per exchange
+    uint64_t xstride = 0;   // bytes per rank buffer
+    uint64_t exchanges = 0;
 };
 
 namespace {
@@ -115,6 +161,14 @@ int fail(yabpe_ctx *c, int code, const char *fmt, ...) {
         if (e__ != hipSuccess)                                                                   \
             return fail((c), YABPE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
                         __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define NCCLCHK(c, call)                                                                            \
+    do {                                                                                           \
+        ncclResult_t r__ = (call);                                                                 \
+        if (r__ != ncclSuccess)                                                                    \
+            return fail((c), YABPE_E_COMM, "%s failed: %s (%s:%d)", #call,                         \
+                        rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "?", __FILE__, __LINE__); \
     } while (0)
 
 template <class T>
@@ -209,22 +263,78 @@ int fold_stats(yabpe_ctx *c) {
     return 0;
 }
 
-// full recount of the resident stream into `t` (zeroed by the caller)
-int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
-    if (c->n_tiles && all_bytes && !c->weighted && optv(c, "dense_count", 1)) {
-        // initial count of the flat layout: every token is still a byte (trainer.py:227-235 over 256 x 256 keys)
-        unsigned long long *dense = nullptr;
-        TRY(dmalloc(c, &dense, 65536));
-        HIPCHK(c, hipMemsetAsync(dense, 0, 65536 * 8, c->stream));
-        const uint32_t bpp = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(c->n_cu / 2, (c->n_tiles + CB_WAVES - 1) / CB_WAVES));
-        CountBytesParams P{c->tiles, c->tile_len, c->n_tiles, dense, bpp};
-        hipLaunchKernelGGL(k_count_bytes, dim3(4 * bpp), dim3(CB_BLOCK), 0, c->stream, P);
-        DenseToTableParams D{dense, t, c->st};
-        hipLaunchKernelGGL(k_dense_to_table, dim3(65536 / BLOCK), dim3(BLOCK), 0, c->stream, D);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfree(dense);
-    } else if (c->n_tiles) {
+// THE collective: every rank contributes `nbytes` from device memory, every rank receives all contributions in
+// rank order.  RCCL all-gather on the compute stream (asynchronous), or the caller's transport (synchronous).
+int comm_allgather(yabpe_ctx *c, const void *send, void *recv, uint64_t nbytes) {
+    if (c->comm) {
+        NCCLCHK(c, rccl()->AllGather(send, recv, nbytes, ncclUint8, c->comm, c->stream));
+        return 0;
+    }
+    if (!c->ag_fn) return fail(c, YABPE_E_COMM, "no transport attached");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = c->ag_fn(c->ag_user, send, recv, nbytes);
+    if (rc != 0) return fail(c, YABPE_E_COMM, "custom all-gather transport failed (%d)", rc);
+    return 0;
+}
+
+int comm_max(yabpe_ctx *c, unsigned long long v, unsigned long long *out);
+
+// All ranks: dump the local table `lt` as records, all-gather them (padded to the largest rank), add every rank's
+// records into `t`.  Used for counts that cannot use the dense byte histogram (weighted words, recounts).
+int exchange_table(yabpe_ctx *c, PairTable lt, uint64_t lcap, PairTable t) {
+    unsigned long long *d_cnt = &c->scratch64[8];
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    // first pass only counts (cap 0), so that every rank learns the padded size
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, lcap / BLOCK));
+    DumpParams D0{lt, nullptr, d_cnt, 0};
+    hipLaunchKernelGGL(k_table_dump, dim3(grid), dim3(BLOCK), 0, c->stream, D0);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long mine = 0, maxn = 0;
+    HIPCHK(c, hipMemcpyAsync(&mine, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    TRY(comm_max(c, mine, &maxn));
+    if (maxn == 0) return 0;
+    uint8_t *send = nullptr, *recv = nullptr;
+    const uint64_t stride = 16 + maxn * sizeof(DeltaRec);
+    TRY(dmalloc(c, &send, stride));
+    TRY(dmalloc(c, &recv, stride * c->n_ranks));
+    HIPCHK(c, hipMemsetAsync(send, 0, 16, c->stream));
+    DumpParams D1{lt, reinterpret_cast<DeltaRec *>(send + 16), reinterpret_cast<unsigned long long *>(send), maxn};
+    hipLaunchKernelGGL(k_table_dump, dim3(grid), dim3(BLOCK), 0, c->stream, D1);
+    HIPCHK(c, hipGetLastError());
+    TRY(comm_allgather(c, send, recv, stride));
+    std::vector<unsigned long long> counts(c->n_ranks);
+    for (int r = 0; r < c->n_ranks; ++r)
+        HIPCHK(c, hipMemcpyAsync(&counts[r], recv + (uint64_t)r * stride, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->n_ranks; ++r) {
+        if (!counts[r]) continue;
+        RecApplyParams A{reinterpret_cast<const DeltaRec *>(recv + (uint64_t)r * stride + 16), counts[r], t, c->st};
+        hipLaunchKernelGGL(k_records_apply, dim3(cdiv64(counts[r], BLOCK)), dim3(BLOCK), 0, c->stream, A);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(send);
+    dfree(recv);
+    return 0;
+}
+
+// max over ranks of a small integer (host-visible); identity on one GPU
+int comm_max(yabpe_ctx *c, unsigned long long v, unsigned long long *out) {
+    *out = v;
+    if (!c->multi) return 0;
+    HIPCHK(c, hipMemcpyAsync(&c->scratch64[7], &v, 8, hipMemcpyHostToDevice, c->stream));
+    TRY(comm_allgather(c, &c->scratch64[7], c->xsmall, 8));
+    std::vector<unsigned long long> all(c->n_ranks);
+    HIPCHK(c, hipMemcpyAsync(all.data(), c->xsmall, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto x : all) *out = std::max(*out, x);
+    return 0;
+}
+
+// pair counts of THIS rank's shard into `t` (zeroed by the caller), generic tokens
+int launch_count_local(yabpe_ctx *c, PairTable t) {
+    if (c->n_tiles) {
         CountParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, t, c->st};
         if (c->weighted)
             hipLaunchKernelGGL(k_count<true>, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
@@ -240,6 +350,69 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
     return 0;
 }
 
+// Full recount of the resident stream -- of ALL ranks' shards when a communicator is attached -- into `t`
+// (zeroed by the caller).  all_bytes: every token is still a byte (initial count of the flat layout).
+int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
+    if (all_bytes && !c->weighted && optv(c, "dense_count", 1)) {
+        // trainer.py:227-235 over 256 x 256 keys: dense LDS histograms, summed across ranks by one all-reduce
+        unsigned long long *dense = nullptr;
+        TRY(dmalloc(c, &dense, 65536));
+        HIPCHK(c, hipMemsetAsync(dense, 0, 65536 * 8, c->stream));
+        if (c->n_tiles) {
+            const uint32_t bpp = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(c->n_cu / 2, (c->n_tiles + CB_WAVES - 1) / CB_WAVES));
+            CountBytesParams P{c->tiles, c->tile_len, c->n_tiles, dense, bpp};
+            hipLaunchKernelGGL(k_count_bytes, dim3(4 * bpp), dim3(CB_BLOCK), 0, c->stream, P);
+        }
+        if (c->multi) {  // sum the per-rank histograms: gather all, add rows
+            unsigned long long *all = nullptr;
+            TRY(dmalloc(c, &all, 65536ull * c->n_ranks));
+            TRY(comm_allgather(c, dense, all, 65536 * 8));
+            hipLaunchKernelGGL(k_sum_rows, dim3(65536 / BLOCK), dim3(BLOCK), 0, c->stream, all, dense, 65536u, (uint32_t)c->n_ranks);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dfree(all);
+        }
+        DenseToTableParams D{dense, t, c->st};
+        hipLaunchKernelGGL(k_dense_to_table, dim3(65536 / BLOCK), dim3(BLOCK), 0, c->stream, D);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(dense);
+        if (c->n_long) {  // long words of this rank (bytes too) -- their pairs go through the generic exchange
+            if (!c->multi) {
+                LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st};
+                hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        if (!c->multi) return 0;
+        // multi-GPU: any rank may hold long words; exchange their pairs generically (usually nothing)
+        unsigned long long any_long = 0;
+        TRY(comm_max(c, c->n_long, &any_long));
+        if (!any_long) return 0;
+        PairTable lt{};
+        HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
+        TRY(table_alloc(c, lt, 1ull << 18, &c->scratch64[9]));
+        if (c->n_long) {
+            LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, lt, c->st};
+            hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+            HIPCHK(c, hipGetLastError());
+        }
+        int rc = exchange_table(c, lt, 1ull << 18, t);
+        table_free(lt);
+        return rc;
+    }
+    if (!c->multi) return launch_count_local(c, t);
+    // generic multi-GPU count: local table -> records -> all-gather -> sum into t
+    PairTable lt{};
+    const uint64_t lcap = (uint64_t)t.mask + 1;
+    HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
+    TRY(table_alloc(c, lt, lcap, &c->scratch64[9]));
+    TRY(launch_count_local(c, lt));
+    int rc = exchange_table(c, lt, lcap, t);
+    table_free(lt);
+    return rc;
+}
+
 // (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
 int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
@@ -251,11 +424,13 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
         c->table_cap = cap;
         TRY(launch_count(c, c->table, all_bytes));
         TRY(state_pull(c));
-        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 2 <= cap) {
+        unsigned long long bad = (c->st_host->halt_req != 0 || c->st_host->table_entries * 2 > cap) ? 1 : 0, any_bad = 0;
+        TRY(comm_max(c, bad, &any_bad));  // replicas differ in layout: all ranks retry together
+        if (!any_bad) {
             c->stats.table_rebuilds++;
             return 0;
         }
-        cap *= (c->st_host->halt_req != 0 || c->st_host->table_entries * 2 > cap) ? 4 : 2;
+        cap *= 4;
         if (cap > (1ull << 31)) break;
     }
     return fail(c, YABPE_E_CAPACITY, "pair table does not fit (more than 2^29 distinct pairs)");
@@ -284,6 +459,21 @@ int table_grow(yabpe_ctx *c, uint64_t new_cap) {
         TRY(state_push(c));
     }
     return fail(c, YABPE_E_CAPACITY, "pair table does not fit");
+}
+
+// (re)allocate the per-iteration exchange buffers for `cap` records per rank
+int comm_buffers(yabpe_ctx *c, uint32_t cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c->xsend);
+    dfree(c->xrecv);
+    c->xsend = c->xrecv = nullptr;
+    c->xcap = cap;
+    c->xstride = 16 + (uint64_t)cap * sizeof(DeltaRec);
+    TRY(dmalloc(c, &c->xsend, c->xstride));
+    TRY(dmalloc(c, &c->xrecv, c->xstride * c->n_ranks));
+    HIPCHK(c, hipMemsetAsync(c->xsend, 0, c->xstride, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->xrecv, 0, c->xstride * c->n_ranks, c->stream));
+    return 0;
 }
 
 int refresh_live_slots(yabpe_ctx *c) {
@@ -404,7 +594,7 @@ int yabpe_create(yabpe_ctx **out, int device_id) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&c->st, sizeof(DevState)) != hipSuccess ||
         hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void **)&c->scratch64, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->scratch64, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->blk_stats, 2 * MAX_APPLY_BLOCKS * sizeof(unsigned long long)) != hipSuccess) {
         int code = fail(nullptr, YABPE_E_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
         yabpe_destroy(c);
@@ -431,6 +621,11 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->blk_stats);
     dfree(c->work);
     dfree(c->work_cnt);
+    table_free(c->delta);
+    dfree(c->xsend);
+    dfree(c->xrecv);
+    dfree(c->xsmall);
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->st_host) (void)hipHostFree(c->st_host);
     for (auto &e : c->events) {
         (void)hipEventDestroy(e.e0);
@@ -523,12 +718,15 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     const uint8_t *d_bytes = nullptr;
     const unsigned long long *d_freq = nullptr;
     void *own_off = nullptr, *own_bytes = nullptr, *own_freq = nullptr;
-    uint64_t total_bytes = 0;
+    uint64_t total_bytes = 0, off_base = 0;
     if (is_device_ptr(word_off)) {
         d_off = (const unsigned long long *)word_off;
         HIPCHK(c, hipMemcpy(&total_bytes, word_off + n_words, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&off_base, word_off, 8, hipMemcpyDeviceToHost));
+        total_bytes -= off_base;
     } else {
-        total_bytes = word_off[n_words];
+        off_base = word_off[0];
+        total_bytes = word_off[n_words] - off_base;
         HIPCHK(c, hipMalloc(&own_off, (n_words + 1) * 8));
         HIPCHK(c, hipMemcpy(own_off, word_off, (n_words + 1) * 8, hipMemcpyHostToDevice));
         d_off = (const unsigned long long *)own_off;
@@ -538,8 +736,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         d_bytes = bytes;
     } else {
         HIPCHK(c, hipMalloc(&own_bytes, total_bytes));
-        HIPCHK(c, hipMemcpy(own_bytes, bytes, total_bytes, hipMemcpyHostToDevice));
-        d_bytes = (const uint8_t *)own_bytes;
+        HIPCHK(c, hipMemcpy(own_bytes, bytes + off_base, total_bytes, hipMemcpyHostToDevice));
+        d_bytes = (const uint8_t *)own_bytes - off_base;  // offsets stay absolute
     }
     if (word_freq) {
         if (is_device_ptr(word_freq)) {
@@ -564,6 +762,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         d_bytes = dd.bytes; d_off = dd.off; d_freq = dd.freq;
         n_words = dd.n_unique;
         total_bytes = dd.total_bytes;
+        off_base = 0;
     }
     c->weighted = d_freq != nullptr;
     c->n_words = n_words;
@@ -598,7 +797,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         dfree(d_long_word);
         TRY(dmalloc(c, &d_long_word, long_cap));
         if (n_words) {
-            LoadParams P{d_bytes, d_off, (unsigned long long)n_words, c->tiles, c->tile_len, c->tile_wbase,
+            LoadParams P{d_bytes, d_off, (unsigned long long)off_base, (unsigned long long)n_words, c->tiles, c->tile_len, c->tile_wbase,
                          (uint32_t *)&c->scratch64[2], &c->scratch64[3], d_long_word, long_cap};
             hipLaunchKernelGGL(k_load_words, dim3(cdiv64(n_words, BLOCK)), dim3(BLOCK), 0, c->stream, P);
             HIPCHK(c, hipGetLastError());
@@ -695,16 +894,18 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
     hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
     SelectParams S{c->partials, c->n_partials, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
-                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table, c->blk_stats, std::max(c->blk_used, 1u)};
+                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
+                   c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u)};
     hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
     hipLaunchKernelGGL(k_rank_update, dim3(cdiv64(tokens_upper, BLOCK)), dim3(BLOCK), 0, c->stream, R);
+    const PairTable out_table = c->multi ? c->delta : c->table;
     if (ev) {
         ev->split = c->split_mode;
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
     if (c->n_tiles) {
-        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, c->table, c->st, c->blk_stats};
+        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats};
         if (!c->split_mode) {
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
@@ -734,8 +935,17 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
     if (c->n_long) {
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, c->table, c->st};
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
         hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+    }
+    if (c->multi) {
+        // this rank's aggregated deltas -> [header | records]; one all-gather; every rank applies all of them
+        ExtractParams X{c->delta, reinterpret_cast<DeltaHdr *>(c->xsend), reinterpret_cast<DeltaRec *>(c->xsend + 16), c->xcap, c->st};
+        hipLaunchKernelGGL(k_delta_extract, dim3((uint32_t)std::max<uint64_t>(1, ((uint64_t)c->delta.mask + 1) / BLOCK / 4)), dim3(BLOCK), 0, c->stream, X);
+        TRY(comm_allgather(c, c->xsend, c->xrecv, c->xstride));
+        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xcap, c->xstride, c->table, c->st};
+        hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xcap, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
+        c->exchanges++;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -831,12 +1041,20 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         TRY(fold_stats(c));
         TRY(state_pull(c));
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
+        if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
+            unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
+            TRY(comm_max(c, sig, &mx));
+            if (mx != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, mx);
+        }
         if (h->halt) {
-            if (h->halt == HALT_TABLE_FULL) {
-                // the stream is consistent (the apply pass finished); only the table lost updates: rebuild it bigger
+            if (h->halt == HALT_TABLE_FULL || h->halt == HALT_DELTA_FULL) {
+                // the streams are consistent (the apply pass finished everywhere); only table updates were lost:
+                // rebuild the table from the token streams, bigger
+                const bool delta_full = h->halt == HALT_DELTA_FULL;
                 h->halt = 0; h->halt_req = 0;
                 TRY(state_push(c));
-                TRY(table_rebuild(c, c->table_cap * 4));
+                if (delta_full) TRY(comm_buffers(c, c->xcap * 4));
+                TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
                 TRY(state_pull(c));
                 i = h->iter - rec_base;  // resume after the last recorded merge
                 continue;
@@ -852,7 +1070,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             break;
         }
         // housekeeping between batches
-        if (h->table_entries * 2 > c->table_cap) TRY(table_grow(c, c->table_cap * 2));
+        if (h->table_entries * 2 > c->table_cap) TRY(table_grow(c, c->table_cap * 2));  // same decision on every rank
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
             TRY(retile_flat(c));
@@ -1035,6 +1253,13 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
     return YABPE_OK;
 }
 
+int yabpe_memcpy_h2d(yabpe_ctx *c, void *dst_dev, const void *src_host, uint64_t n) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst_dev, src_host, n, hipMemcpyHostToDevice));
+    return YABPE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- synthetic corpus
 int yabpe_synth_generate(yabpe_ctx *c, uint64_t target_bytes, uint32_t n_types, uint64_t seed, const uint8_t *alphabet,
                          uint32_t alphabet_len, int space_prefix, uint8_t **out_dev_bytes, uint64_t **out_dev_off,
@@ -1063,12 +1288,56 @@ int yabpe_synth_free(yabpe_ctx *c) {
 
 // ---------------------------------------------------------------------------------------------- multi-GPU (see yabpe_comm.h)
 int yabpe_comm_unique_id(uint8_t out_id[128]) {
-    (void)out_id;
-    return YABPE_E_COMM;
+    if (!out_id) return YABPE_E_INVALID;
+    Rccl *R = rccl();
+    if (!R) return fail(nullptr, YABPE_E_COMM, "librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, YABPE_E_COMM, "ncclGetUniqueId failed");
+    memcpy(out_id, &id, 128);
+    return YABPE_OK;
 }
+
+static int comm_attach(yabpe_ctx *c, int rank, int n_ranks) {
+    if (c->have_words) return fail(c, YABPE_E_INVALID, "attach the communicator before yabpe_load_words");
+    if (c->comm || c->ag_fn) return fail(c, YABPE_E_INVALID, "communicator already attached");
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    return 0;
+}
+static int comm_finish(yabpe_ctx *c) {
+    const uint64_t dcap = 1ull << optv(c, "delta_table_log2", 14);
+    TRY(table_alloc(c, c->delta, dcap, &c->st->delta_entries));
+    TRY(dmalloc(c, &c->xsmall, (uint64_t)c->n_ranks));
+    TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 2048)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return YABPE_OK;
+}
+
 int yabpe_comm_init(yabpe_ctx *c, int rank, int n_ranks, const uint8_t unique_id[128]) {
-    (void)rank; (void)n_ranks; (void)unique_id;
-    return fail(c, YABPE_E_COMM, "multi-GPU exchange not built yet");
+    if (!c || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(comm_attach(c, rank, n_ranks));
+    if (n_ranks == 1 && !optv(c, "force_comm", 0)) return YABPE_OK;
+    c->multi = true;
+    Rccl *R = rccl();
+    if (!R) return fail(c, YABPE_E_COMM, "librccl.so could not be loaded");
+    ncclUniqueId id;
+    memcpy(&id, unique_id, 128);
+    NCCLCHK(c, R->CommInitRank(&c->comm, n_ranks, id, rank));
+    return comm_finish(c);
+}
+
+int yabpe_comm_init_custom(yabpe_ctx *c, int rank, int n_ranks, yabpe_allgather_fn fn, void *user) {
+    if (!c || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(comm_attach(c, rank, n_ranks));
+    if (n_ranks == 1 && !optv(c, "force_comm", 0)) return YABPE_OK;
+    c->multi = true;
+    c->ag_fn = fn;
+    c->ag_user = user;
+    return comm_finish(c);
 }
 
 }  // extern "C"

@@ -71,6 +71,16 @@ struct Best {
     uint32_t pad;
 };
 
+// multi-GPU delta exchange records (see k_delta_extract)
+struct DeltaHdr {
+    unsigned long long count; // records this rank produced (may exceed the buffer capacity: overflow)
+    unsigned long long halt;  // this rank's halt request
+};
+struct DeltaRec {
+    uint32_t key, pad;
+    long long delta;
+};
+
 __device__ __forceinline__ uint32_t hash32(uint32_t k) {
     k ^= k >> 16;
     k *= 0x7feb352dU;
@@ -1017,6 +1027,7 @@ struct SelectParams {
     unsigned long long *rec_live_slots; // live slots read by iteration i's apply pass
     uint32_t rec_base;                  // iter value at the start of this yabpe_train call
     PairTable table;                    // the selected pair's entry is zeroed here
+    DeltaHdr *delta_hdr;                // multi-GPU: this rank's send header (count reset here), else NULL
     unsigned long long *blk_stats;      // per-workgroup counters of the last k_apply
     uint32_t n_blk;
 };
@@ -1064,6 +1075,10 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
     const int tid = threadIdx.x;
     if (tid == 0) {
         if (st->halt == 0 && st->halt_req != 0) st->halt = st->halt_req;
+        // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
+        // no replica can run out of probes on its own.
+        if (st->halt == 0 && st->table_entries * 4ull > ((unsigned long long)P.table.mask + 1ull) * 3ull) st->halt = HALT_TABLE_FULL;
+        if (P.delta_hdr) P.delta_hdr->count = 0ull;
         s_flag = st->done | st->halt;
     }
     __syncthreads();
@@ -1213,6 +1228,7 @@ __global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) {
 struct LoadParams {
     const uint8_t *bytes;
     const unsigned long long *off;
+    unsigned long long off_base; // off[0]: offsets may be a slice of a larger corpus (word sharding)
     unsigned long long n_words;
     uint16_t *tiles;
     uint32_t *tile_len;
@@ -1229,7 +1245,7 @@ __global__ __launch_bounds__(BLOCK) void k_load_words(LoadParams P) {
     if (w >= P.n_words) return;
     const unsigned long long o0 = P.off[w], o1 = P.off[w + 1];
     const unsigned long long L = o1 - o0;
-    const unsigned long long pos = o0 + w; // packed position: every earlier word contributed its bytes + 1 SEP
+    const unsigned long long pos = (o0 - P.off_base) + w; // packed position: every earlier word contributed its bytes + 1 SEP
     const unsigned long long tile = pos / SPAN;
     const uint32_t slot = (uint32_t)(pos - tile * SPAN);
     uint16_t *dst = P.tiles + tile * CAP + slot;
@@ -1322,6 +1338,100 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(RehashParams P) {
         const long long v = (long long)P.from.cnt[s];
         if (v != 0) gt_add(P.to, P.st, k, v);
     }
+}
+
+// ================================================================ multi-GPU: exchange of aggregated pair-count deltas
+// Every rank owns a shard of the words and a replica of the pair table.  Its apply pass adds into a small per-rank
+// delta table; k_delta_extract turns that into [header | records], one RCCL all-gather moves all ranks' buffers,
+// k_delta_apply adds every rank's records into the replica.  Integer sums are order-independent, so all replicas
+// hold identical counts and every rank selects the same merge.  A rank that must stop (overflow) says so in its
+// header: all ranks then stop at the same iteration.
+
+struct ExtractParams {
+    PairTable dt;
+    DeltaHdr *hdr;
+    DeltaRec *rec;
+    uint32_t cap;
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_delta_extract(ExtractParams P) {
+    const uint32_t slots = P.dt.mask + 1;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < slots; s += gridDim.x * BLOCK) {
+        const uint32_t k = P.dt.keys[s];
+        if (k == EMPTY) continue;
+        const long long v = (long long)P.dt.cnt[s];
+        P.dt.keys[s] = EMPTY; // the delta table is empty again for the next merge
+        P.dt.cnt[s] = 0ull;
+        if (v != 0) {
+            const unsigned long long idx = atomicAdd(&P.hdr->count, 1ull);
+            if (idx < P.cap) P.rec[idx] = DeltaRec{k, 0u, v};
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.hdr->halt = P.st->halt | P.st->halt_req;
+        P.st->delta_entries = 0ull;
+    }
+}
+
+struct DeltaApplyParams {
+    const uint8_t *recv; // n_ranks buffers of stride bytes: DeltaHdr, then cap DeltaRec
+    uint32_t n_ranks, cap;
+    unsigned long long stride;
+    PairTable table;
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t r = (uint32_t)(idx / P.cap), j = (uint32_t)(idx % P.cap);
+    if (r >= P.n_ranks) return;
+    const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
+    const unsigned long long n = h->count;
+    if (j == 0) {
+        if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
+        else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
+    }
+    if (j < n && j < P.cap) {
+        const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
+        gt_add(P.table, P.st, rec[j].key, rec[j].delta);
+    }
+}
+
+// out[i] = sum over rows r of in[r * n + i]
+__global__ void k_sum_rows(const unsigned long long *in, unsigned long long *out, uint32_t n, uint32_t rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = 0;
+    for (uint32_t r = 0; r < rows; ++r) s += in[(size_t)r * n + i];
+    out[i] = s;
+}
+
+// all entries of a table as records (for the global recount exchange)
+struct DumpParams {
+    PairTable t;
+    DeltaRec *rec;
+    unsigned long long *count;
+    unsigned long long cap;
+};
+__global__ __launch_bounds__(BLOCK) void k_table_dump(DumpParams P) {
+    const uint32_t slots = P.t.mask + 1;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < slots; s += gridDim.x * BLOCK) {
+        const uint32_t k = P.t.keys[s];
+        if (k == EMPTY) continue;
+        const long long v = (long long)P.t.cnt[s];
+        if (v == 0) continue;
+        const unsigned long long idx = atomicAdd(P.count, 1ull);
+        if (idx < P.cap) P.rec[idx] = DeltaRec{k, 0u, v};
+    }
+}
+struct RecApplyParams {
+    const DeltaRec *rec;
+    unsigned long long n;
+    PairTable table;
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_records_apply(RecApplyParams P) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < P.n) gt_add(P.table, P.st, P.rec[i].key, P.rec[i].delta);
 }
 
 // ================================================================ debug: compare two pair tables

@@ -32,13 +32,15 @@ class Stats(ctypes.Structure):
 
 
 _lib = None
+# int fn(void *user, const void *send_dev, void *recv_dev, uint64_t nbytes)  (include/yabpe.h: yabpe_allgather_fn)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
 
 # every symbol include/yabpe.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
     "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
     "yabpe_iter_log", "yabpe_event_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
-    "yabpe_memcpy_d2h", "yabpe_comm_unique_id", "yabpe_comm_init",
+    "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
 ]
 
 
@@ -72,8 +74,10 @@ def lib() -> ctypes.CDLL:
                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_free.argtypes = [c_void_p]
         L.yabpe_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
+        L.yabpe_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
         L.yabpe_comm_unique_id.argtypes = [c_void_p]
         L.yabpe_comm_init.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        L.yabpe_comm_init_custom.argtypes = [c_void_p, c_int, c_int, ALLGATHER_FN, c_void_p]
         if L.yabpe_abi_version() != 1:
             raise ImportError("libyabpe.so ABI version mismatch")
         _lib = L
@@ -215,6 +219,37 @@ class Context:
 
     def synth_free(self) -> None:
         self._chk(lib().yabpe_synth_free(self._h))
+
+    def h2d(self, dev_ptr: int, arr: np.ndarray) -> None:
+        arr = np.ascontiguousarray(arr)
+        self._chk(lib().yabpe_memcpy_h2d(self._h, c_void_p(dev_ptr), arr.ctypes.data, arr.nbytes))
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (c_uint8 * 128)()
+        rc = lib().yabpe_comm_unique_id(buf)
+        if rc != 0:
+            raise YabpeError(rc, lib().yabpe_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, rank: int, n_ranks: int, unique_id: bytes) -> None:
+        """RCCL transport (one process per GPU).  Call before load_words."""
+        assert len(unique_id) == 128
+        buf = (c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(lib().yabpe_comm_init(self._h, rank, n_ranks, buf))
+
+    def comm_init_custom(self, rank: int, n_ranks: int, allgather) -> None:
+        """Custom transport: allgather(send_dev_ptr, recv_dev_ptr, nbytes) -> 0 on success."""
+        def _cb(_user, send, recv, nbytes):
+            try:
+                return int(allgather(send, recv, nbytes) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._ag_cb = ALLGATHER_FN(_cb)  # keep alive
+        self._chk(lib().yabpe_comm_init_custom(self._h, rank, n_ranks, self._ag_cb, None))
 
     def d2h(self, dev_ptr: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
         out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)

@@ -1,0 +1,161 @@
+"""Multi-GPU driver: one process per GPU, words sharded by contiguous ranges, pair-count deltas exchanged with one
+all-gather per merge (RCCL over xGMI from inside libyabpe.so; see include/yabpe.h "Multi-GPU").
+
+The reference has no distributed code at all; this is new design.  Words are independent units --
+pairs never cross a word (reference trainer.py:232) -- so any partition of the words gives the same global counts.
+`torch.distributed` is used only for the rendezvous (broadcast of the 128-byte RCCL id) and, in tests, as a
+stand-in transport.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Sequence
+
+import numpy as np
+
+
+def plan_shards(off: np.ndarray, world: int) -> list[tuple[int, int]]:
+    """Contiguous word ranges [w0, w1) per rank, balanced by resident slots (bytes + one separator per word).
+
+    off: u64 offsets (n_words + 1), host array."""
+    n = len(off) - 1
+    base = int(off[0])
+    total = int(off[n]) - base + n
+    bounds = [0]
+    packed = off.astype(np.int64) - base + np.arange(n + 1, dtype=np.int64)  # monotone
+    for r in range(1, world):
+        bounds.append(int(np.searchsorted(packed, (total * r) // world, side="left")))
+    bounds.append(n)
+    bounds = [min(max(b, 0), n) for b in bounds]
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def plan_shards_device(read_off: Callable[[int], int], n_words: int, world: int) -> list[tuple[int, int]]:
+    """Same plan for an offsets array that lives on the device: read_off(i) returns off[i] (a few dozen reads)."""
+    base = read_off(0)
+    total = read_off(n_words) - base + n_words
+    bounds = [0]
+    for r in range(1, world):
+        target = (total * r) // world
+        lo, hi = 0, n_words
+        while lo < hi:  # first w with (off[w] - base + w) >= target
+            mid = (lo + hi) // 2
+            if read_off(mid) - base + mid >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        bounds.append(max(lo, bounds[-1]))
+    bounds.append(n_words)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+class TorchTransport:
+    """yabpe_allgather_fn over torch.distributed (any backend).  Used by the tests to run several ranks on one GPU
+    (gloo); production uses RCCL inside the library instead.  to_host/to_dev move bytes between the "device"
+    buffers the library hands out and host memory."""
+
+    def __init__(self, to_host: Callable[[int, int], np.ndarray], to_dev: Callable[[int, np.ndarray], None], group=None):
+        self.to_host, self.to_dev, self.group = to_host, to_dev, group
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, send_ptr: int, recv_ptr: int, nbytes: int) -> int:
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group)
+        mine = torch.from_numpy(self.to_host(send_ptr, nbytes).copy())
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, mine, group=self.group)
+        self.to_dev(recv_ptr, torch.cat(parts).numpy())
+        self.calls += 1
+        self.bytes += nbytes * world
+        return 0
+
+
+def host_memory_transport(group=None) -> TorchTransport:
+    """Transport whose "device" pointers are plain host addresses (CPU-only tests of the callback plumbing)."""
+    def to_host(ptr, n):
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr)).copy()
+
+    def to_dev(ptr, arr):
+        ctypes.memmove(ptr, arr.ctypes.data, arr.nbytes)
+
+    return TorchTransport(to_host, to_dev, group)
+
+
+def attach(ctx, rank: int, world: int, transport: str = "rccl") -> None:
+    """Attach a communicator to a _native.Context (before load_words).  transport: "rccl" | "torch"."""
+    if world == 1:
+        return
+    import torch
+    import torch.distributed as dist
+
+    if transport == "rccl":
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.tensor(list(ctx.comm_unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, src=0)
+        ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
+    elif transport == "torch":
+        ctx.comm_init_custom(rank, world, TorchTransport(lambda p, n: ctx.d2h(p, n), lambda p, a: ctx.h2d(p, a)))
+    else:
+        raise ValueError(transport)
+
+
+def train_sharded(ctx_factory, flat: np.ndarray, off: np.ndarray, freq, base_tokens: Sequence[bytes], num_merges: int,
+                  min_frequency: int, rank: int, world: int, transport: str = "rccl", options: dict | None = None):
+    """Host arrays: every rank passes the SAME full corpus; each loads its own shard.  Returns
+    (left, right, merged, count, stats)."""
+    shards = plan_shards(off, world)
+    w0, w1 = shards[rank]
+    with ctx_factory() as ctx:
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_vocab(list(base_tokens))
+        attach(ctx, rank, world, transport)
+        sub_off = off[w0:w1 + 1]
+        sub_freq = None if freq is None else freq[w0:w1]
+        ctx.load_words(flat, sub_off, sub_freq)
+        left, right, merged, count = ctx.train(num_merges, min_frequency)
+        return left, right, merged, count, ctx.stats()
+
+
+class ShardedRunner:
+    """bench.py helper: the corpus is already on every rank's GPU; each rank trains on its word range."""
+
+    def __init__(self, gen_ctx, bytes_ptr: int, off_ptr: int, n_words: int, n_bytes: int, base_tokens, rank: int,
+                 world: int, local_rank: int, transport: str = "rccl"):
+        self.bytes_ptr, self.off_ptr, self.base = bytes_ptr, off_ptr, list(base_tokens)
+        self.rank, self.world, self.local_rank, self.transport = rank, world, local_rank, transport
+
+        def read_off(i: int) -> int:
+            return int(gen_ctx.d2h(off_ptr + 8 * i, 8, dtype=np.uint64)[0])
+
+        self.w0, self.w1 = plan_shards_device(read_off, n_words, world)[rank]
+
+    def _context(self):
+        """One context + communicator for all jobs (RCCL communicator creation is not part of a training job)."""
+        from . import _native
+
+        if getattr(self, "_ctx", None) is None:
+            self._ctx = _native.Context(self.local_rank)
+            self._ctx.set_vocab(self.base)
+            attach(self._ctx, self.rank, self.world, self.transport)
+        return self._ctx
+
+    def run(self, num_merges: int, min_frequency: int, dedup: bool = False, event_sample: int = 0) -> dict:
+        ctx = self._context()
+        ctx.set_option("event_sample", event_sample)
+        ctx.set_vocab(self.base)  # resets tokens / merge state; the communicator stays attached
+        ctx.load_words_ptr(self.bytes_ptr, self.off_ptr + 8 * self.w0, self.w1 - self.w0, dedup=dedup)
+        left, right, merged, count = ctx.train(num_merges, min_frequency)
+        return {"n_merges": len(left), "stats": ctx.stats(), "left": left, "right": right, "merged": merged}
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None:
+            self._ctx.close()
+            self._ctx = None
