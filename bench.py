@@ -75,12 +75,20 @@ def main() -> None:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     import torch
 
+    # Rehearsal switch (not used by the driver): YABPE_BENCH_REHEARSAL=1 runs all ranks on GPU 0 with gloo and the
+    # torch transport, to exercise the multi-rank bench flow on a 1-GPU box (RCCL refuses two ranks on one device).
+    rehearsal = os.environ.get("YABPE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from yet_another_bpe import _native, synth
 
@@ -96,7 +104,8 @@ def main() -> None:
     if world > 1:
         from yet_another_bpe import distributed as ydist
 
-        runner = ydist.ShardedRunner(gen, pb, po, n_words, n_bytes, base, rank, world, local_rank)
+        runner = ydist.ShardedRunner(gen, pb, po, n_words, n_bytes, base, rank, world, local_rank,
+                                     transport="torch" if rehearsal else "rccl")
         runner._context()  # rendezvous + RCCL communicator before the timed region
     else:
         runner = None
@@ -136,7 +145,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -174,10 +183,19 @@ def main() -> None:
             "actual_stream_GBps": round(actual / secs / 1e9, 1),
             "actual_frac_of_peak": round(actual / secs / 1e9 / HBM_PEAK_GBS, 4),
             "apply_phase_avg_us": round(1e3 * st["apply_ms_sampled"] / st["apply_launches_sampled"], 2),
+            "traffic_source": None,
             "note": "achieved = sum 2*(T_i+W) over the HIP-event-timed launches / their summed duration (SURVEY 8d: T_i live tokens, "
                     "W words); actual_* counts the u16 slots the kernel really reads (single-token words are dropped from the "
                     "stream, so actual < algorithmic); apply_phase = k_scan + k_slow (or the fused k_apply)",
         }
+    if "roofline" in out and out["roofline"]["kernel"] == "k_scan":
+        # HBM bytes per k_scan launch from PMC counters cannot be collected inside this process; they come from the
+        # committed summary of tools/collect_pmc.sh run on this same command (separate FETCH_SIZE / WRITE_SIZE passes)
+        pmc = sorted((REPO / "profiles").glob("r*_pmc_k_scan_full_summary.json"))
+        if pmc and args.target_mib == 1024 and args.merges == 32000 and world == 1:
+            d = json.loads(pmc[-1].read_text())
+            out["roofline"]["traffic"] = int(d["traffic_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name} (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
     if rank == 0 and not args.no_dedup_line and world == 1:
         t1 = time.perf_counter()
         rd = one_job(True, 0)
