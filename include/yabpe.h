@@ -109,6 +109,9 @@ typedef struct yabpe_stats_t {
     uint64_t scan_launches_sampled;
     uint64_t scan_algo_bytes_sampled;
     uint64_t scan_actual_bytes_sampled;
+    /* skip index: launches of k_scan_skip and the tiles they actually read (the rest was skipped by signature) */
+    uint64_t scan_skip_launches;
+    uint64_t scan_skip_tiles_read;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

@@ -157,6 +157,11 @@ def test_many_tiles_retile_and_table_growth():
                                               "retile_min_tiles": 16, "apply_blocks": 3})
     assert (v2, m2) == (exp_vocab, exp_merges)
     assert s2["retiles"] >= 1
+    # the plain streaming scan (skip index off) and the always-split / never-split forms give the same result
+    for opts in ({"skip_index": 0}, {"split": 1}, {"split": 0}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16}):
+        v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
+        assert (v3, m3) == (exp_vocab, exp_merges), opts
+    assert s1["scan_skip_launches"] > 0 and s1["scan_skip_tiles_read"] < s1["scan_skip_launches"] * s1["n_tiles"]
     assert s1["tokens_initial"] - s1["tokens_now"] == s2["tokens_initial"] - s2["tokens_now"]
 
 

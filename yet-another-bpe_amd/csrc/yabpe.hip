@@ -40,8 +40,23 @@ Rccl *rccl() {
     static bool tried = false;
     if (!tried) {
         tried = true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // A process can hold two ROCm stacks (the system one and the copy bundled with PyTorch).  RCCL must be the
+        // one that sits next to the HIP runtime THIS library is bound to, or it will not see our device.
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        for (const auto &name : names) {
+            r.h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
         }
         if (r.h) {
@@ -126,6 +141,11 @@ struct yabpe_ctx {
     uint64_t work_cap = 0;
     bool split_mode = false;
     std::vector<float> ev_scan_us;
+    // skip index
+    uint32_t *sig = nullptr;
+    uint32_t sig_stride = 0;
+    unsigned long long *blk_read = nullptr;  // [MAX_LISTS] tiles read by k_scan_skip, accumulated
+    uint64_t scan_skip_launches = 0;
     // multi-GPU
     int rank = 0, n_ranks = 1;
     bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
@@ -489,7 +509,8 @@ int refresh_live_slots(yabpe_ctx *c) {
 
 void free_corpus(yabpe_ctx *c) {
     dfree(c->tiles); dfree(c->tiles_alt); dfree(c->tile_len); dfree(c->tile_len_alt);
-    dfree(c->tile_wbase); dfree(c->tile_wbase_alt); dfree(c->wfreq);
+    dfree(c->tile_wbase); dfree(c->tile_wbase_alt); dfree(c->wfreq); dfree(c->sig);
+    c->sig = nullptr; c->sig_stride = 0;
     dfree(c->long_tok); dfree(c->long_off); dfree(c->long_len); dfree(c->long_freq);
     c->tiles = c->tiles_alt = nullptr;
     c->tile_len = c->tile_len_alt = c->tile_wbase = c->tile_wbase_alt = c->wfreq = nullptr;
@@ -507,6 +528,21 @@ void free_records(yabpe_ctx *c) {
     c->rec_cap = 0;
 }
 
+
+// (Re)compute every tile's signature from the resident stream (after load and after a retile).
+int build_signatures(yabpe_ctx *c) {
+    if (!optv(c, "skip_index", 1) || c->n_tiles == 0) return 0;
+    if (!c->sig || c->sig_stride < c->n_tiles) {
+        dfree(c->sig);
+        c->sig = nullptr;
+        c->sig_stride = c->n_tiles;
+        TRY(dmalloc(c, &c->sig, (uint64_t)SIG_WORDS * c->sig_stride));
+    }
+    SigParams P{c->tiles, c->tile_len, c->n_tiles, c->sig, c->sig_stride};
+    hipLaunchKernelGGL(k_build_sig, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 
 // Repack the live words of the flat layout into fresh, densely filled tiles (drops dead/empty words and PAD).
 // The apply kernel reads tile prefixes only, so this is what keeps its traffic proportional to live tokens.
@@ -550,6 +586,7 @@ int retile_flat(yabpe_ctx *c) {
     dfree(kept);
     dfree(base);
     TRY(refresh_live_slots(c));
+    TRY(build_signatures(c));
     c->stats.retiles++;
     return 0;
 }
@@ -621,6 +658,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->blk_stats);
     dfree(c->work);
     dfree(c->work_cnt);
+    dfree(c->blk_read);
     table_free(c->delta);
     dfree(c->xsend);
     dfree(c->xrecv);
@@ -850,6 +888,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     h->table_entries = 0;
     TRY(state_push(c));
     TRY(refresh_live_slots(c));
+    TRY(build_signatures(c));
     TRY(table_rebuild(c, 1ull << 18, /*all_bytes=*/true));  // 65,536 possible byte pairs: start at load <= 1/4
     c->stats.table_rebuilds = 0;
     HIPCHK(c, hipEventRecord(ev1, c->stream));
@@ -869,6 +908,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.scan_launches_sampled = 0;
     c->stats.scan_algo_bytes_sampled = 0;
     c->stats.scan_actual_bytes_sampled = 0;
+    c->scan_skip_launches = 0;
+    if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
     return YABPE_OK;
@@ -886,6 +927,8 @@ static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
     if (!c->work_cnt) {
         TRY(dmalloc(c, &c->work_cnt, MAX_LISTS));
         HIPCHK(c, hipMemsetAsync(c->work_cnt, 0, MAX_LISTS * 4, c->stream));
+        TRY(dmalloc(c, &c->blk_read, MAX_LISTS));
+        HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     }
     return 0;
 }
@@ -905,7 +948,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
     if (c->n_tiles) {
-        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats};
+        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats, c->sig, c->sig_stride};
         if (!c->split_mode) {
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
@@ -916,11 +959,22 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         } else {
             // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
             const uint32_t want = (c->n_tiles + WPB - 1) / WPB;
-            const uint32_t scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 8)), MAX_LISTS));
-            const uint32_t seg = WPB * ((c->n_tiles + scan_grid * WPB - 1) / (scan_grid * WPB));
-            TRY(ensure_worklist(c, scan_grid, seg));
-            ScanParams SP{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg};
-            hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
+            uint32_t scan_grid, seg;
+            if (c->sig) {
+                const uint32_t n_chunks = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+                scan_grid = std::max(1u, std::min<uint32_t>(n_chunks, MAX_LISTS));
+                seg = SCAN_CHUNK * ((n_chunks + scan_grid - 1) / scan_grid);
+                TRY(ensure_worklist(c, scan_grid, seg));
+                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, c->sig, c->sig_stride, c->blk_read};
+                hipLaunchKernelGGL(k_scan_skip, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
+                c->scan_skip_launches++;
+            } else {
+                scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 4)), MAX_LISTS));
+                seg = WPB * ((c->n_tiles + scan_grid * WPB - 1) / (scan_grid * WPB));
+                TRY(ensure_worklist(c, scan_grid, seg));
+                ScanParams SP{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg};
+                hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
+            }
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
             const uint32_t slow_grid = std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
             c->blk_used = std::max(c->blk_used, slow_grid);
@@ -1180,6 +1234,13 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.live_slots = c->st_host->live_slots;
     c->stats.table_capacity = c->table_cap;
     c->stats.table_entries = c->st_host->table_entries;
+    c->stats.scan_skip_launches = c->scan_skip_launches;
+    c->stats.scan_skip_tiles_read = 0;
+    if (c->blk_read) {
+        std::vector<unsigned long long> br(MAX_LISTS);
+        HIPCHK(c, hipMemcpy(br.data(), c->blk_read, MAX_LISTS * 8, hipMemcpyDeviceToHost));
+        for (auto v : br) c->stats.scan_skip_tiles_read += v;
+    }
     *out = c->stats;
     return YABPE_OK;
 }

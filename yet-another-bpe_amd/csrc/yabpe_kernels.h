@@ -32,6 +32,8 @@ constexpr int AGG_N = 1024;          // LDS delta-aggregator entries per workgro
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PADPAD = (YB_PAD << 16) | YB_PAD;
 constexpr int LONG_CH = 4096;        // long-word path: tokens per LDS chunk
+constexpr int SIG_WORDS = 64;        // tile signature: 2,048-bit set of the token ids present in the tile
+constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4 };
 
@@ -89,6 +91,10 @@ __device__ __forceinline__ uint32_t hash32(uint32_t k) {
     k ^= k >> 16;
     return k;
 }
+
+// Tile signatures (skip index).  sig[w * stride + tile], w < SIG_WORDS: transposed, so that the threads of a workgroup
+// that test 256 consecutive tiles read consecutive words.  Bit of token t:
+__device__ __forceinline__ uint32_t sig_bit(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - 11); } // 0 .. 2047
 
 // Within one wave LDS operations complete in order; this keeps the compiler from moving a lane's LDS reads
 // above other lanes' LDS writes.
@@ -324,6 +330,8 @@ struct ApplyParams {
     PairTable out; // where deltas go: the pair table (1 GPU) or the per-rank delta table (multi-GPU)
     DevState *st;
     unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
+    uint32_t *sig;                 // tile signatures (may be NULL)
+    uint32_t sig_stride;
 };
 
 // lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
@@ -368,6 +376,7 @@ struct WaveLds {
     uint32_t dpref[CAP / 32 + 1];      // exclusive popcount prefix of dmask
     uint32_t smask[CAP / 32];          // weighted: SEP bitmap
     uint32_t spref[CAP / 32];          // weighted: exclusive popcount prefix of smask
+    uint32_t sig[SIG_WORDS];           // signature of the rewritten tile
 };
 
 struct MrgBits {
@@ -596,7 +605,29 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
     }
     const uint32_t pad_end = (new_len + 7u) & ~7u;
     if (lane < 8 && new_len + lane < pad_end) W.out[new_len + lane] = YB_PAD;
+    if (P.sig) { // exact signature of the rewritten tile: every kept token, with c at the sites
+        W.sig[lane] = 0u; // SIG_WORDS == 64
+        wave_sync();
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            const int p0 = seg ? pB : pA;
+            if ((uint32_t)p0 < len) {
+                const uint4 &v = seg ? r.vb : r.va;
+                const uint32_t sm = seg ? mB : mA;
+                const uint32_t db = (W.dmask[p0 >> 5] >> (p0 & 31)) & 0xffu;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = ((sm >> j) & 1u) ? c : elem16(v, j);
+                    if (!((db >> j) & 1u) && (uint32_t)(p0 + j) < len && x < YB_PAD) {
+                        const uint32_t h = sig_bit(x);
+                        atomicOr(&W.sig[h >> 5], 1u << (h & 31));
+                    }
+                }
+            }
+        }
+    }
     wave_sync();
+    if (P.sig) P.sig[(size_t)lane * P.sig_stride + tile] = W.sig[lane];
     uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
     if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(W.out + pA);
     if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(W.out + pB);
@@ -732,6 +763,121 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
     }
     __syncthreads();
     if (threadIdx.x == 0) P.work_cnt[blockIdx.x] = s_n;
+}
+
+// ---------------------------------------------------------------- skip index: signatures and the scan that uses them
+struct SigParams {
+    const uint16_t *tiles;
+    const uint32_t *tile_len;
+    uint32_t n_tiles;
+    uint32_t *sig;
+    uint32_t sig_stride;
+};
+__global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
+    __shared__ uint32_t s_sig[WPB][SIG_WORDS];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *sg = s_sig[wib];
+    const uint32_t stride = gridDim.x * WPB;
+    for (uint32_t tile = blockIdx.x * WPB + wib; tile < P.n_tiles; tile += stride) {
+        const uint32_t len = P.tile_len[tile];
+        sg[lane] = 0u;
+        wave_sync();
+        if (len) {
+            const TileRegs r = load_tile(P.tiles, tile, len, lane);
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg) {
+                const uint4 &v = seg ? r.vb : r.va;
+                const uint32_t p0 = seg ? 512 + lane * 8 : lane * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = elem16(v, j);
+                    if (p0 + j < len && x < YB_PAD) {
+                        const uint32_t h = sig_bit(x);
+                        atomicOr(&sg[h >> 5], 1u << (h & 31));
+                    }
+                }
+            }
+        }
+        wave_sync();
+        P.sig[(size_t)lane * P.sig_stride + tile] = sg[lane];
+        wave_sync();
+    }
+}
+
+// Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
+// tile's signature (12 B per tile: length + the two words holding bit(a) and bit(b)); the tiles that may contain
+// both tokens are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
+struct ScanSkipParams {
+    ScanParams S;
+    const uint32_t *sig;
+    uint32_t sig_stride;
+    unsigned long long *blk_read; // [gridDim.x] tiles actually read (statistics; plain stores)
+};
+
+__global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
+    __shared__ uint32_t s_n, s_hits;
+    __shared__ uint2 s_list[SCAN_CHUNK];
+    const ScanParams &P = Q.S;
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    const uint32_t a = st->a, b = st->b;
+    const uint32_t mk = yb_memkey(a, b);
+    const uint32_t ha = sig_bit(a), hb = sig_bit(b);
+    const uint32_t *sa = Q.sig + (size_t)(ha >> 5) * Q.sig_stride;
+    const uint32_t *sb = Q.sig + (size_t)(hb >> 5) * Q.sig_stride;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        s_hits = 0;
+    }
+    __syncthreads();
+    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
+    unsigned long long n_read = 0;
+    const uint32_t n_chunks = (P.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
+        uint32_t len = 0;
+        bool maybe = false;
+        if (t < P.n_tiles) {
+            len = P.tile_len[t];
+            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & 1u);
+        }
+        const unsigned long long m = __ballot(maybe);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (maybe) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(t, len);
+        __syncthreads();
+        const uint32_t n = s_n;
+        n_read += n;
+        // the candidate tiles, dealt to the waves; the next candidate's data is in flight while one is matched
+        uint32_t j = wib;
+        uint2 item = j < n ? s_list[j] : make_uint2(0u, 0u);
+        TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
+        while (j < n) {
+            const uint2 cur = item;
+            const TileRegs r = nxt;
+            j += WPB;
+            if (j < n) {
+                item = s_list[j];
+                nxt = load_tile(P.tiles, item.x, item.y, lane);
+            }
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        P.work_cnt[blockIdx.x] = s_hits;
+        if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
+    }
 }
 
 // ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
