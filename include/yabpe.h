@@ -118,8 +118,9 @@ int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 int yabpe_iter_log(yabpe_ctx *ctx, uint64_t *out_sites, uint64_t *out_live_slots, uint32_t cap, uint32_t *out_n);
 
 /* Per-launch HIP-event timings of k_apply from the last yabpe_train call (option "event_sample" = N times every
-   Nth launch): iteration index (relative to the call) and duration in microseconds. */
-int yabpe_event_log(yabpe_ctx *ctx, uint32_t *out_iter, float *out_us, uint32_t cap, uint32_t *out_n);
+   Nth launch): iteration index (relative to the call), duration of the whole apply phase and of its streaming
+   kernel (k_scan / k_scan_skip, or the fused k_apply) in microseconds. */
+int yabpe_event_log(yabpe_ctx *ctx, uint32_t *out_iter, float *out_us, float *out_scan_us, uint32_t cap, uint32_t *out_n);
 
 /* Debug / self-check: recount every pair from the token stream into a scratch table and compare with the
    incrementally maintained table.  *out_mismatches = number of differing keys. */

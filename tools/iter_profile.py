@@ -28,13 +28,24 @@ with _native.Context() as g:
         ctx.load_words_ptr(pb, po, nw)
         left, right, merged, count = ctx.train(a.merges, 1)
         sites, live = ctx.iter_log()
-        it, us = ctx.event_log()
+        it, us, scan = ctx.event_log()
         st = ctx.stats()
 Path(a.out).parent.mkdir(parents=True, exist_ok=True)
 with open(a.out, "w") as f:
-    f.write("iter,live_slots,sites,count,apply_us,GBps_actual\n")
-    for i, u in zip(it.tolist(), us.tolist()):
-        f.write(f"{i},{live[i]},{sites[i]},{count[i]},{u:.2f},{2*live[i]/u/1e3:.1f}\n")
+    f.write("iter,live_slots,sites,count,apply_us,scan_us,left_len,right_len\n")
+    tl = [1] * 70000
+    for k, (l, r, m) in enumerate(zip(left.tolist(), right.tolist(), merged.tolist())):
+        if m < len(tl) and m >= 257:
+            tl[m] = tl[l] + tl[r]
+    for i, u, sc in zip(it.tolist(), us.tolist(), scan.tolist()):
+        f.write(f"{i},{live[i]},{sites[i]},{count[i]},{u:.2f},{sc:.2f},{tl[left[i]]},{tl[right[i]]}\n")
+print("skip launches", st["scan_skip_launches"], "tiles read", st["scan_skip_tiles_read"], "avg pass", st["scan_skip_tiles_read"] / max(1, st["scan_skip_launches"]) / max(1, st["n_tiles"]))
+import collections
+late = [(tl[left[i]] == 1 and tl[right[i]] == 1, sc, u) for i, u, sc in zip(it.tolist(), us.tolist(), scan.tolist()) if i >= 1000]
+for flag in (True, False):
+    xs = [x for x in late if x[0] == flag]
+    if xs:
+        print("iters>=1000", "byte-byte" if flag else "other", len(xs), "scan avg us", sum(x[1] for x in xs) / len(xs), "apply avg us", sum(x[2] for x in xs) / len(xs))
 print("train_ms", st["train_ms"], "apply_ms_sampled", st["apply_ms_sampled"], "scan_ms_sampled", st["scan_ms_sampled"], "scan_launches", st["scan_launches_sampled"], "n", len(it), "retiles", st["retiles"], "rebuilds", st["table_rebuilds"], "table_cap", st["table_capacity"], "entries", st["table_entries"])
 sel = [0, 1, 2, 5, 10, 20, 50, 100, 200, 400, 800, 1200, 1600, 2000, 2400, 2800, 2999, 5000, 10000, 20000, 31999]
 for i in sel:

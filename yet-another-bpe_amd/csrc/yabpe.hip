@@ -146,6 +146,8 @@ struct yabpe_ctx {
     uint32_t sig_stride = 0;
     unsigned long long *blk_read = nullptr;  // [MAX_LISTS] tiles read by k_scan_skip, accumulated
     uint64_t scan_skip_launches = 0;
+    bool sig_valid = false;
+    uint32_t sig_built_at = 0;
     // multi-GPU
     int rank = 0, n_ranks = 1;
     bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
@@ -586,7 +588,7 @@ int retile_flat(yabpe_ctx *c) {
     dfree(kept);
     dfree(base);
     TRY(refresh_live_slots(c));
-    TRY(build_signatures(c));
+    if (c->sig_valid) TRY(build_signatures(c));
     c->stats.retiles++;
     return 0;
 }
@@ -888,7 +890,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     h->table_entries = 0;
     TRY(state_push(c));
     TRY(refresh_live_slots(c));
-    TRY(build_signatures(c));
+    c->sig_valid = false;
     TRY(table_rebuild(c, 1ull << 18, /*all_bytes=*/true));  // 65,536 possible byte pairs: start at load <= 1/4
     c->stats.table_rebuilds = 0;
     HIPCHK(c, hipEventRecord(ev1, c->stream));
@@ -948,7 +950,8 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
     if (c->n_tiles) {
-        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats, c->sig, c->sig_stride};
+        ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats,
+                      c->split_mode ? c->sig : nullptr, c->sig_stride};  // signatures are maintained in the split form only
         if (!c->split_mode) {
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
@@ -959,14 +962,33 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         } else {
             // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
             const uint32_t want = (c->n_tiles + WPB - 1) / WPB;
-            uint32_t scan_grid, seg;
-            if (c->sig) {
+            uint32_t scan_grid = 0, seg = 0;
+            const bool use_sig = c->sig && c->sig_valid;
+            if (use_sig && optv(c, "fuse_skip", 0)) {
+                // signatures + rewrite in one launch, dynamically scheduled
+                const uint32_t n_chunks = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+                const uint32_t grid = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)optv(c, "apply_skip_blocks", (int64_t)c->n_cu * 6)));
+                c->blk_used = std::max(c->blk_used, grid);
+                TRY(ensure_worklist(c, 1, 1));
+                ApplySkipParams AS{P, n_chunks, c->blk_read};
+                if (c->weighted)
+                    hipLaunchKernelGGL(k_apply_skip<true>, dim3(grid), dim3(BLOCK), 0, c->stream, AS);
+                else
+                    hipLaunchKernelGGL(k_apply_skip<false>, dim3(grid), dim3(BLOCK), 0, c->stream, AS);
+                c->scan_skip_launches++;
+                if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+            } else {
+            if (use_sig) {
                 const uint32_t n_chunks = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
                 scan_grid = std::max(1u, std::min<uint32_t>(n_chunks, MAX_LISTS));
                 seg = SCAN_CHUNK * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
-                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, c->sig, c->sig_stride, c->blk_read};
-                hipLaunchKernelGGL(k_scan_skip, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
+                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read};
+                c->blk_used = std::max(c->blk_used, scan_grid);
+                if (!c->weighted && optv(c, "inline_single", 1))
+                    hipLaunchKernelGGL(k_scan_skip<true>, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
+                else
+                    hipLaunchKernelGGL(k_scan_skip<false>, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
                 c->scan_skip_launches++;
             } else {
                 scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 4)), MAX_LISTS));
@@ -983,6 +1005,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 hipLaunchKernelGGL(k_slow<true>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
             else
                 hipLaunchKernelGGL(k_slow<false>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
+            }
         }
     } else if (ev) {
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
@@ -1030,6 +1053,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     c->ev_us.clear();
     c->ev_scan_us.clear();
     c->split_mode = false;
+    c->sig_valid = false;
     if (num_merges == 0) return YABPE_OK;
 
     if (c->rec_cap < num_merges) {
@@ -1076,6 +1100,15 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->split_mode = split_opt == 1;
         else if (!c->split_mode && h->iter > rec_base && h->best_count * 2 < c->n_tiles)
             c->split_mode = true;
+        if (c->split_mode && optv(c, "skip_index", 1)) {
+            // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
+            const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 4096));
+            if (!c->sig_valid || i - c->sig_built_at >= every) {
+                TRY(build_signatures(c));
+                c->sig_valid = true;
+                c->sig_built_at = i;
+            }
+        }
         uint32_t batch_end = std::min(num_merges, i + ((i == 0 && !c->split_mode) ? std::min<uint32_t>(check, 8) : check));
         for (; i < batch_end; ++i) {
             EventPair *ev = nullptr;
@@ -1254,11 +1287,12 @@ int yabpe_iter_log(yabpe_ctx *c, uint64_t *out_sites, uint64_t *out_live_slots, 
     return YABPE_OK;
 }
 
-int yabpe_event_log(yabpe_ctx *c, uint32_t *out_iter, float *out_us, uint32_t cap, uint32_t *out_n) {
+int yabpe_event_log(yabpe_ctx *c, uint32_t *out_iter, float *out_us, float *out_scan_us, uint32_t cap, uint32_t *out_n) {
     if (!c || !out_n) return YABPE_E_INVALID;
     uint32_t n = std::min<uint32_t>(cap, (uint32_t)c->ev_iter.size());
     if (out_iter) memcpy(out_iter, c->ev_iter.data(), (size_t)n * 4);
     if (out_us) memcpy(out_us, c->ev_us.data(), (size_t)n * 4);
+    if (out_scan_us) memcpy(out_scan_us, c->ev_scan_us.data(), (size_t)n * 4);
     *out_n = (uint32_t)c->ev_iter.size();
     return YABPE_OK;
 }
@@ -1313,6 +1347,12 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
     HIPCHK(c, hipMemcpy(dst_host, src_dev, n, hipMemcpyDeviceToHost));
     return YABPE_OK;
 }
+
+#ifdef YB_PROFILE_SLOW
+int yabpe_debug_slow_profile(unsigned long long out[8]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_slow_prof), 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int yabpe_memcpy_h2d(yabpe_ctx *c, void *dst_dev, const void *src_host, uint64_t n) {
     if (!c) return YABPE_E_INVALID;

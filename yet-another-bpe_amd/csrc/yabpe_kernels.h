@@ -32,7 +32,9 @@ constexpr int AGG_N = 1024;          // LDS delta-aggregator entries per workgro
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PADPAD = (YB_PAD << 16) | YB_PAD;
 constexpr int LONG_CH = 4096;        // long-word path: tokens per LDS chunk
-constexpr int SIG_WORDS = 64;        // tile signature: 2,048-bit set of the token ids present in the tile
+constexpr int TOK_WORDS = 64;        // tile signature, part 1: 2,048-bit set of the token ids present in the tile
+constexpr int PAIR_WORDS = 128;      // part 2: 4,096-bit set of the adjacent pairs present in the tile
+constexpr int SIG_WORDS = TOK_WORDS + PAIR_WORDS;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4 };
@@ -55,6 +57,7 @@ struct DevState {
     unsigned long long tokens_now; // T_i
     unsigned long long delta_entries;
     unsigned long long best_count; // count of the merge being applied
+    uint32_t chunk_next[8];        // k_apply_skip: dynamic chunk queues (sharded 8 ways), reset by k_select
 };
 
 struct PairTable {
@@ -93,8 +96,24 @@ __device__ __forceinline__ uint32_t hash32(uint32_t k) {
 }
 
 // Tile signatures (skip index).  sig[w * stride + tile], w < SIG_WORDS: transposed, so that the threads of a workgroup
-// that test 256 consecutive tiles read consecutive words.  Bit of token t:
+// that test 256 consecutive tiles read consecutive words.  Rows [0, TOK_WORDS): token bits; rows [TOK_WORDS, SIG_WORDS):
+// pair bits.  A signature is a SUPERSET of what the tile holds: bits are added when a rewrite creates a token / pair
+// and only a rebuild (k_build_sig) clears stale ones.
 __device__ __forceinline__ uint32_t sig_bit(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - 11); } // 0 .. 2047
+__device__ __forceinline__ uint32_t pair_bit(uint32_t key) { // key = left << 16 | right ; 0 .. 4095
+    uint32_t k = key * 0x9E3779B1u;
+    k ^= k >> 15;
+    k *= 0x85EBCA77u;
+    return k >> (32 - 12);
+}
+__device__ __forceinline__ void sig_set_tok(uint32_t *sig, uint32_t stride, uint32_t tile, uint32_t t) {
+    const uint32_t h = sig_bit(t);
+    atomicOr(&sig[(size_t)(h >> 5) * stride + tile], 1u << (h & 31));
+}
+__device__ __forceinline__ void sig_set_pair(uint32_t *sig, uint32_t stride, uint32_t tile, uint32_t key) {
+    const uint32_t h = pair_bit(key);
+    atomicOr(&sig[(size_t)(TOK_WORDS + (h >> 5)) * stride + tile], 1u << (h & 31));
+}
 
 // Within one wave LDS operations complete in order; this keeps the compiler from moving a lane's LDS reads
 // above other lanes' LDS writes.
@@ -162,10 +181,35 @@ __device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *
     gt_add(t, st, key, d); // aggregator full around this hash: go straight to HBM
 }
 
+// slot of `key` in the LDS aggregator (inserting it), or AGG_N when the probe window is full
+template <class V>
+__device__ __forceinline__ uint32_t agg_slot(Agg<V> g, uint32_t key) {
+    uint32_t s = hash32(key) & (AGG_N - 1);
+#pragma unroll 1
+    for (int probe = 0; probe < 8; ++probe) {
+        uint32_t k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == EMPTY) {
+            k = atomicCAS(&g.keys[s], EMPTY, key);
+            if (k == EMPTY) k = key;
+        }
+        if (k == key) return s;
+        s = (s + 1) & (AGG_N - 1);
+    }
+    return AGG_N;
+}
+
+// Wave-uniform memo of the last key seen in each of the four delta roles (old/new pair on the left/right of a site)
+// and its aggregator slot.  Within one merge nearly every site carries the same four keys, so after the first tile a
+// delta costs one fire-and-forget LDS add instead of a probe (load, compare-and-swap, add: three dependent LDS trips).
+struct KeyMemo {
+    uint32_t key[4];
+    uint32_t slot[4];
+};
+
 // Flat layout: lanes of one wave usually carry the same few keys (Zipf) -- peel the hottest keys off with
 // ballots so that one lane adds the wave's total instead of 64 lanes serialising on one LDS address.
 __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, DevState *st, bool valid, uint32_t key,
-                                             int sign, int lane) {
+                                             int sign, int lane, KeyMemo &memo, int role) {
     unsigned long long pend = __ballot(valid);
 #pragma unroll 1
     for (int r = 0; r < 3 && pend; ++r) {
@@ -175,7 +219,24 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
         const unsigned long long same = __ballot(mine);
         const unsigned long long plus = __ballot(mine && sign > 0);
         const int sum = __popcll(plus) - __popcll(same & ~plus);
-        if (lane == leader && sum != 0) agg_add(g, t, st, k, (long long)sum);
+        if (sum != 0) {
+            uint32_t slot;
+            if (memo.key[role] == k) { // wave-uniform
+                slot = memo.slot[role];
+            } else {
+                uint32_t sl = 0;
+                if (lane == leader) sl = agg_slot(g, k);
+                slot = __builtin_amdgcn_readlane(sl, leader);
+                memo.key[role] = k;
+                memo.slot[role] = slot;
+            }
+            if (lane == leader) {
+                if (slot < (uint32_t)AGG_N)
+                    atomicAdd(&g.vals[slot], sum);
+                else
+                    gt_add(t, st, k, (long long)sum); // aggregator full around this hash: straight to HBM
+            }
+        }
         pend &= ~same;
         if (mine) valid = false;
     }
@@ -187,7 +248,11 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
     for (int i = threadIdx.x; i < AGG_N; i += BLOCK) {
         uint32_t k = g.keys[i];
         long long v = (long long)g.vals[i];
+#ifndef YB_DBG_NOFLUSH
         if (k != EMPTY && v != 0) gt_add(t, st, k, v);
+#else
+        if (k == 12345u && v == 77) gt_add(t, st, k, v);
+#endif
     }
 }
 
@@ -368,15 +433,17 @@ __device__ __forceinline__ uint32_t elem16(const uint4 &v, int j) {
 
 // per-wave LDS scratch of the slow path
 struct WaveLds {
-    uint16_t stage[8 + CAP + 8];       // tokens with PAD halo; position q at stage[8 + q]
-    uint16_t out[CAP];                 // compacted tile
+    uint16_t stage[8 + CAP + 8];       // tokens with PAD halo; position q at stage[8 + q].  The compacted tile is
+                                       // built in place at stage + 8 once the last neighbour lookup is done.
     unsigned long long mb[CAP / 64 + 2]; // a == b only: site bitmap by 64-position rounds
     uint32_t mbits[1 + CAP / 32 + 1];  // site bitmap, word w at mbits[1 + w], zero halo words
     uint32_t dmask[CAP / 32 + 1];      // drop bitmap
     uint32_t dpref[CAP / 32 + 1];      // exclusive popcount prefix of dmask
     uint32_t smask[CAP / 32];          // weighted: SEP bitmap
     uint32_t spref[CAP / 32];          // weighted: exclusive popcount prefix of smask
-    uint32_t sig[SIG_WORDS];           // signature of the rewritten tile
+#ifdef YB_PROFILE_SLOW
+    unsigned long long prof[8];
+#endif
 };
 
 struct MrgBits {
@@ -384,16 +451,23 @@ struct MrgBits {
     __device__ __forceinline__ int operator()(int q) const { return (int)((mbits[1 + (q >> 5)] >> (q & 31)) & 1u); }
 };
 
+// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar): Hillis-Steele inside each row of 16
+// lanes (row_shr 1,2,4,8; lanes without a source add 0), then the row totals travel with row_bcast:15 / row_bcast:31.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // exclusive prefix of popcounts over the 32 words of a bitmap (lanes 0..31 hold one word each)
 __device__ __forceinline__ uint32_t bitmap_prefix(uint32_t word, int lane, uint32_t *total) {
-    uint32_t pc = lane < 32 ? __popc(word) : 0u;
-    uint32_t inc = pc;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        uint32_t u = __shfl_up(inc, o);
-        if ((lane & 63) >= o) inc += u;
-    }
-    *total = __shfl(inc, 31);
+    const uint32_t pc = lane < 32 ? __popc(word) : 0u;
+    const uint32_t inc = wave_inclusive_sum(pc);
+    *total = __builtin_amdgcn_readlane(inc, 63);
     return inc - pc;
 }
 
@@ -458,6 +532,18 @@ __global__ __launch_bounds__(BLOCK) void k_dense_to_table(DenseToTableParams P) 
     if (v) gt_add(P.table, P.st, yb_pairkey(i >> 8, i & 255u), (long long)v);
 }
 
+#ifdef YB_PROFILE_SLOW
+__device__ unsigned long long g_slow_prof[8]; // [0] tiles, [1..5] cycles per phase
+#define YB_STAMP(i)                                                                     \
+    do {                                                                                \
+        unsigned long long t__ = __builtin_readcyclecounter();                          \
+        if (lane == 0) W.prof[i] += t__ - t_prev;                                       \
+        t_prev = t__;                                                                   \
+    } while (0)
+#else
+#define YB_STAMP(i) do { } while (0)
+#endif
+
 // What a workgroup needs to run the slow path
 template <class AggV>
 struct SlowCtx {
@@ -466,12 +552,135 @@ struct SlowCtx {
     DevState *st;
     uint32_t a, b, c, mk, self;
     int lane;
+    KeyMemo memo; // wave-uniform
 };
+
+// slot q of the tile (wave-uniform q), read out of the registers that hold the tile: lane (q>>3)&63 owns it
+__device__ __forceinline__ uint32_t tile_elem_uniform(const TileRegs &r, int q) {
+    if (q < 0 || q >= CAP) return YB_PAD;
+    const bool segB = q >= 512;
+    const int l = (q >> 3) & 63, e = q & 7;
+    uint32_t d;
+    switch (e >> 1) {
+        case 0: d = segB ? r.vb.x : r.va.x; break;
+        case 1: d = segB ? r.vb.y : r.va.y; break;
+        case 2: d = segB ? r.vb.z : r.va.z; break;
+        default: d = segB ? r.vb.w : r.va.w; break;
+    }
+    const uint32_t w = __builtin_amdgcn_readlane(d, l);
+    return (e & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// The common case of the rewrite (flat layout, a != b): the tile holds exactly ONE site.  Everything is wave-uniform:
+// the site and its neighbours come out of the registers with v_readlane, the four deltas go through the key memo, and
+// the compaction is a funnel shift in registers -- the slots that leave the tile are one contiguous run (the b, or the
+// whole word (c, b, SEP) when the word was exactly (a b)), so every later slot moves left by the same s in {1, 3}.
+// No LDS staging, no bitmaps, no scatter.
+template <class AggV>
+__device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile, uint32_t len, const TileRegs &r,
+                                                 int lane_s, uint32_t mm_s, unsigned long long &wave_sites,
+                                                 unsigned long long &wave_freed) {
+    const ApplyParams &P = C.P;
+    DevState *st = C.st;
+    const uint32_t a = C.a, b = C.b, c = C.c;
+    const int lane = C.lane;
+    const int j = __ffs((int)mm_s) - 1;
+    const int p = j < 8 ? lane_s * 8 + j : 512 + lane_s * 8 + (j - 8); // the site (wave-uniform)
+    const uint32_t L = tile_elem_uniform(r, p - 1), R = tile_elem_uniform(r, p + 2);
+    const bool left = L < YB_PAD, right = R < YB_PAD;
+    const bool dead = !left && R == YB_SEP; // the word was exactly (a b): it leaves the stream (yb_site_word_dies)
+
+    // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1
+    auto upd = [&](uint32_t key, int sign, int role) {
+        uint32_t slot;
+        if (C.memo.key[role] == key) {
+            slot = C.memo.slot[role];
+        } else {
+            uint32_t sl = 0;
+            if (lane == 0) sl = agg_slot(C.agg, key);
+            slot = __builtin_amdgcn_readfirstlane(sl);
+            C.memo.key[role] = key;
+            C.memo.slot[role] = slot;
+        }
+        if (lane == 0) {
+            if (slot < (uint32_t)AGG_N)
+                atomicAdd(&C.agg.vals[slot], (AggV)sign);
+            else
+                gt_add(P.out, st, key, (long long)sign);
+        }
+    };
+    if (left) {
+        upd(yb_pairkey(L, a), -1, 0);
+        upd(yb_pairkey(L, c), +1, 1);
+    }
+    if (right) {
+        upd(yb_pairkey(b, R), -1, 2);
+        upd(yb_pairkey(c, R), +1, 3);
+    }
+    if (P.sig && lane == 0 && !dead) {
+        sig_set_tok(P.sig, P.sig_stride, tile, c);
+        if (left) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(L, c));
+        if (right) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(c, R));
+    }
+
+    // ---- compaction in registers
+    const int D0 = dead ? p : p + 1; // first slot that leaves
+    const int s = dead ? 3 : 1;      // how many leave (contiguous)
+    const uint32_t new_len = len - (uint32_t)s;
+    const uint32_t pad_end = (new_len + 7u) & ~7u;
+    uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+    // the first dwords of segment B (for segment A's lane 63)
+    const uint32_t fx = __builtin_amdgcn_readfirstlane(r.vb.x), fy = __builtin_amdgcn_readfirstlane(r.vb.y);
+    const uint32_t fz = __builtin_amdgcn_readfirstlane(r.vb.z);
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const int g0 = seg ? 512 + lane * 8 : lane * 8;
+        const uint4 v = seg ? r.vb : r.va;
+        // window of 7 dwords: own 4 + the next group's first 3 (enough for s <= 3)
+        const uint32_t n0 = next_lane(v.x, seg ? PADPAD : fx);
+        const uint32_t n1 = next_lane(v.y, seg ? PADPAD : fy);
+        const uint32_t n2 = next_lane(v.z, seg ? PADPAD : fz);
+        uint32_t U0 = v.x, U1 = v.y, U2 = v.z, U3 = v.w;
+        if (!dead && p >= g0 && p < g0 + 8) { // this lane's group holds the site: a -> c
+            const int e = p - g0;
+            const uint32_t m = (e & 1) ? 0xffff0000u : 0x0000ffffu;
+            const uint32_t cv = (e & 1) ? (c << 16) : c;
+            if ((e >> 1) == 0) U0 = (U0 & ~m) | cv;
+            else if ((e >> 1) == 1) U1 = (U1 & ~m) | cv;
+            else if ((e >> 1) == 2) U2 = (U2 & ~m) | cv;
+            else U3 = (U3 & ~m) | cv;
+        }
+        uint32_t S0, S1, S2, S3; // the group as it looks when every slot comes from s positions to the right
+        if (s == 1) {
+            S0 = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+            S1 = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+            S2 = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+            S3 = __builtin_amdgcn_alignbit(n0, v.w, 16);
+        } else {
+            S0 = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+            S1 = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+            S2 = __builtin_amdgcn_alignbit(n0, v.w, 16);
+            S3 = __builtin_amdgcn_alignbit(n1, n0, 16);
+        }
+        (void)n2;
+        // slots before D0 keep their place, slots from D0 on take the shifted value
+        const int bd = D0 - g0; // number of leading slots of this group that stay
+        auto mix = [&](uint32_t U, uint32_t S, int i) -> uint32_t {
+            const uint32_t m = ((2 * i < bd) ? 0x0000ffffu : 0u) | ((2 * i + 1 < bd) ? 0xffff0000u : 0u);
+            return (U & m) | (S & ~m);
+        };
+        const uint4 o = make_uint4(mix(U0, S0, 0), mix(U1, S1, 1), mix(U2, S2, 2), mix(U3, S3, 3));
+        if (g0 + 8 > p && (uint32_t)g0 < pad_end) wb[(seg ? 64 : 0) + lane] = o; // groups from the first changed slot on
+    }
+    if (lane == 0) P.tile_len[tile] = new_len;
+    wave_sites += 1;
+    wave_freed += (unsigned long long)s;
+}
 
 // Rewrites one tile that contains at least one candidate site: pair-count deltas, drop bitmap, compaction,
 // write-back.  Work is proportional to the number of sites.  Returns false when nothing changed.
 template <bool WEIGHTED, class AggV>
-__device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
+__device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
                                           uint32_t na, uint32_t nb, unsigned long long &wave_sites,
                                           unsigned long long &wave_freed) {
     const ApplyParams &P = C.P;
@@ -482,13 +691,31 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
     TokAt T{stg};
     MrgBits M{W.mbits};
     const int pA = lane * 8, pB = 512 + lane * 8; // first positions of this lane's two segments
-    wave_sync();
-    stage_tile(stg, r, lane);
+#ifdef YB_PROFILE_SLOW
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    if (lane == 0) W.prof[0] += 1ull;
+#endif
     uint32_t mA, mB; // site masks of the two segments
     if (a != b) {
         mA = match_mask8(r.va, na, mk);
         mB = match_mask8(r.vb, nb, mk);
-    } else { // greedy parity rule over runs of a (trainer.py:276-285): through the round bitmaps
+        if (!WEIGHTED) {
+            const uint32_t mine = mA | (mB << 8);
+            const unsigned long long holders = __ballot(mine != 0);
+            if (__popcll(holders) == 1) {
+                const int lane_s = __ffsll((long long)holders) - 1;
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s);
+                if (__popc(mm_s) == 1) {
+                    single_site_tile(C, tile, len, r, lane_s, mm_s, wave_sites, wave_freed);
+                    return true;
+                }
+            }
+        }
+        wave_sync();
+        stage_tile(stg, r, lane);
+    } else {
+        wave_sync();
+        stage_tile(stg, r, lane); // greedy parity rule over runs of a (trainer.py:276-285): through the round bitmaps
         wave_sync();
         const int rounds = (len + 63) >> 6;
         const unsigned long long any = mark_sites(stg, W.mb, rounds, a, b, lane);
@@ -519,8 +746,10 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
         if (lane < 32) W.spref[lane] = pre;
         wave_sync();
     }
+    YB_STAMP(1);
     // ---- deltas + drop marks: each lane walks its own sites (usually none or one)
     uint32_t mm = mA | (mB << 8);
+    if (P.sig && lane == 0) sig_set_tok(P.sig, P.sig_stride, tile, c); // the tile now holds c
     {
         uint32_t tot = __popc(mm);
 #pragma unroll
@@ -537,6 +766,10 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
         d.lo = d.ln = d.ro = d.rn = 0;
         if (site) {
             yb_site_deltas(p, a, b, c, T, M, d);
+            if (P.sig) { // the pairs this site creates are now present in the tile
+                if (d.left) sig_set_pair(P.sig, P.sig_stride, tile, d.ln);
+                if (d.right) sig_set_pair(P.sig, P.sig_stride, tile, d.rn);
+            }
             atomicOr(&W.dmask[(p + 1) >> 5], 1u << ((p + 1) & 31));
             if (!WEIGHTED && yb_site_word_dies(p, T)) {
                 atomicOr(&W.dmask[p >> 5], 1u << (p & 31));
@@ -558,13 +791,14 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
                 }
             }
         } else {
-            agg_add_wave(C.agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane);
-            agg_add_wave(C.agg, P.out, st, d.left, d.ln, +1, lane);
-            agg_add_wave(C.agg, P.out, st, d.right && d.ro != self, d.ro, -1, lane);
-            agg_add_wave(C.agg, P.out, st, d.right, d.rn, +1, lane);
+            agg_add_wave(C.agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane, C.memo, 0);
+            agg_add_wave(C.agg, P.out, st, d.left, d.ln, +1, lane, C.memo, 1);
+            agg_add_wave(C.agg, P.out, st, d.right && d.ro != self, d.ro, -1, lane, C.memo, 2);
+            agg_add_wave(C.agg, P.out, st, d.right, d.rn, +1, lane, C.memo, 3);
         }
     }
     wave_sync();
+    YB_STAMP(2);
     // ---- compaction: every kept element moves left by the number of dropped elements before it
     uint32_t dropped;
     {
@@ -572,6 +806,7 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
         if (lane < 32) W.dpref[lane] = pre;
     }
     wave_sync();
+    uint16_t *outb = W.stage + 8; // (all reads of the staged tokens are done: the site loop is behind us)
     const uint32_t new_len = len - dropped;
     uint32_t first_drop = CAP; // first changed position: 16-B groups before it are unchanged in HBM
     {
@@ -584,55 +819,35 @@ __device__ __forceinline__ bool slow_tile(const SlowCtx<AggV> &C, WaveLds &W, ui
         // a site at p rewrites slot p (a -> c) and drops p+1: the first CHANGED slot can be first_drop - 1
         if (first_drop > 0) first_drop -= 1;
     }
-#pragma unroll
-    for (int seg = 0; seg < 2; ++seg) {
-        const int p0 = seg ? pB : pA;
-        if ((uint32_t)p0 < len && (uint32_t)p0 + 8 > first_drop) {
-            const uint4 &v = seg ? r.vb : r.va;
-            const uint32_t sm = seg ? mB : mA;
-            const uint32_t dw = W.dmask[p0 >> 5];
-            uint32_t shift = W.dpref[p0 >> 5] + __popc(dw & ((1u << (p0 & 31)) - 1u));
-            const uint32_t db = (dw >> (p0 & 31)) & 0xffu;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if ((db >> j) & 1u) {
-                    ++shift;
-                } else if ((uint32_t)(p0 + j) < len) {
-                    W.out[p0 + j - shift] = (uint16_t)(((sm >> j) & 1u) ? c : elem16(v, j));
-                }
-            }
+    // Position-parallel, in place: in round k lane l handles position 64k + l, so LDS reads and writes of a round
+    // touch consecutive addresses (no bank conflicts); an element never moves right, and every round reads its 64
+    // inputs before writing, so later rounds still find their inputs untouched.  Rounds before the first change are
+    // skipped: their slots already hold the right values (only 16-B groups from first_drop on are stored to HBM).
+    {
+        const int k0 = (int)(first_drop >> 6), k1 = (int)((len + 63u) >> 6);
+        for (int k = k0; k < k1; ++k) {
+            const int p = k * 64 + lane;
+            const uint32_t v = stg[8 + p];
+            const uint32_t dw = W.dmask[p >> 5], mw = W.mbits[1 + (p >> 5)];
+            const uint32_t below = (1u << (p & 31)) - 1u;
+            const bool drop = ((dw >> (p & 31)) & 1u) || (uint32_t)p >= len;
+            const uint32_t dst = (uint32_t)p - (W.dpref[p >> 5] + __popc(dw & below));
+            const uint32_t val = ((mw >> (p & 31)) & 1u) ? c : v;
+            wave_sync();
+            if (!drop) outb[dst] = (uint16_t)val;
+            wave_sync();
         }
     }
     const uint32_t pad_end = (new_len + 7u) & ~7u;
-    if (lane < 8 && new_len + lane < pad_end) W.out[new_len + lane] = YB_PAD;
-    if (P.sig) { // exact signature of the rewritten tile: every kept token, with c at the sites
-        W.sig[lane] = 0u; // SIG_WORDS == 64
-        wave_sync();
-#pragma unroll
-        for (int seg = 0; seg < 2; ++seg) {
-            const int p0 = seg ? pB : pA;
-            if ((uint32_t)p0 < len) {
-                const uint4 &v = seg ? r.vb : r.va;
-                const uint32_t sm = seg ? mB : mA;
-                const uint32_t db = (W.dmask[p0 >> 5] >> (p0 & 31)) & 0xffu;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t x = ((sm >> j) & 1u) ? c : elem16(v, j);
-                    if (!((db >> j) & 1u) && (uint32_t)(p0 + j) < len && x < YB_PAD) {
-                        const uint32_t h = sig_bit(x);
-                        atomicOr(&W.sig[h >> 5], 1u << (h & 31));
-                    }
-                }
-            }
-        }
-    }
+    if (lane < 8 && new_len + lane < pad_end) outb[new_len + lane] = YB_PAD;
     wave_sync();
-    if (P.sig) P.sig[(size_t)lane * P.sig_stride + tile] = W.sig[lane];
+    YB_STAMP(3);
     uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-    if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(W.out + pA);
-    if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(W.out + pB);
+    if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(outb + pA);
+    if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(outb + pB);
     if (lane == 0) P.tile_len[tile] = new_len;
     wave_freed += dropped;
+    YB_STAMP(4);
     return true;
 }
 
@@ -645,6 +860,9 @@ __device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
         W.mbits[0] = 0;
         W.mbits[1 + CAP / 32] = 0;
     }
+#ifdef YB_PROFILE_SLOW
+    if (lane < 8) W.prof[lane] = 0ull;
+#endif
 }
 
 // per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
@@ -677,7 +895,8 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
     if (st->done | st->halt) return;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane};
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
     const uint32_t mk = C.mk;
@@ -712,6 +931,9 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
             slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
         }
     }
+#ifdef YB_PROFILE_SLOW
+    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
+#endif
     apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
 }
 
@@ -781,60 +1003,82 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
     const uint32_t stride = gridDim.x * WPB;
     for (uint32_t tile = blockIdx.x * WPB + wib; tile < P.n_tiles; tile += stride) {
         const uint32_t len = P.tile_len[tile];
-        sg[lane] = 0u;
+        for (int w = lane; w < SIG_WORDS; w += 64) sg[w] = 0u;
         wave_sync();
         if (len) {
             const TileRegs r = load_tile(P.tiles, tile, len, lane);
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg) {
                 const uint4 &v = seg ? r.vb : r.va;
+                const uint32_t nx = (seg ? nb : na) & 0xffffu;
                 const uint32_t p0 = seg ? 512 + lane * 8 : lane * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t x = elem16(v, j);
+                    const uint32_t y = j < 7 ? elem16(v, j + 1) : nx;
                     if (p0 + j < len && x < YB_PAD) {
                         const uint32_t h = sig_bit(x);
                         atomicOr(&sg[h >> 5], 1u << (h & 31));
+                        if (y < YB_PAD) {
+                            const uint32_t hp = pair_bit(yb_pairkey(x, y));
+                            atomicOr(&sg[TOK_WORDS + (hp >> 5)], 1u << (hp & 31));
+                        }
                     }
                 }
             }
         }
         wave_sync();
-        P.sig[(size_t)lane * P.sig_stride + tile] = sg[lane];
+        for (int w = lane; w < SIG_WORDS; w += 64) P.sig[(size_t)w * P.sig_stride + tile] = sg[w];
         wave_sync();
     }
 }
 
 // Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
-// tile's signature (12 B per tile: length + the two words holding bit(a) and bit(b)); the tiles that may contain
-// both tokens are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
+// tile's signature (16 B per tile: length + the words holding bit(a), bit(b) and bit(a,b)); the tiles that may contain
+// the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
 struct ScanSkipParams {
     ScanParams S;
-    const uint32_t *sig;
-    uint32_t sig_stride;
+    ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
     unsigned long long *blk_read; // [gridDim.x] tiles actually read (statistics; plain stores)
 };
 
+// INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
+// (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
+template <bool INLINE>
 __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     __shared__ uint32_t s_n, s_hits;
     __shared__ uint2 s_list[SCAN_CHUNK];
+    __shared__ uint32_t s_keys[INLINE ? AGG_N : 1];
+    __shared__ int s_vals[INLINE ? AGG_N : 1];
+    __shared__ unsigned long long s_cnt[2];
     const ScanParams &P = Q.S;
     DevState *st = P.st;
     if (st->done | st->halt) return;
-    const uint32_t a = st->a, b = st->b;
-    const uint32_t mk = yb_memkey(a, b);
-    const uint32_t ha = sig_bit(a), hb = sig_bit(b);
-    const uint32_t *sa = Q.sig + (size_t)(ha >> 5) * Q.sig_stride;
-    const uint32_t *sb = Q.sig + (size_t)(hb >> 5) * Q.sig_stride;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<int> C{Q.A, Agg<int>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                   KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    const uint32_t a = C.a, b = C.b;
+    const uint32_t mk = yb_memkey(a, b);
+    C.mk = mk;
+    C.self = yb_pairkey(a, b);
+    const bool do_inline = INLINE && a != b;
+    const uint32_t ha = sig_bit(a), hb = sig_bit(b), hp = pair_bit(yb_pairkey(a, b));
+    const uint32_t *sa = Q.A.sig + (size_t)(ha >> 5) * Q.A.sig_stride;
+    const uint32_t *sb = Q.A.sig + (size_t)(hb >> 5) * Q.A.sig_stride;
+    const uint32_t *sp = Q.A.sig + (size_t)(TOK_WORDS + (hp >> 5)) * Q.A.sig_stride;
+    if (INLINE) agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         s_n = 0;
         s_hits = 0;
     }
     __syncthreads();
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
-    unsigned long long n_read = 0;
+    unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t n_chunks = (P.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
@@ -842,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         bool maybe = false;
         if (t < P.n_tiles) {
             len = P.tile_len[t];
-            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & 1u);
+            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & (sp[t] >> (hp & 31)) & 1u);
         }
         const unsigned long long m = __ballot(maybe);
         uint32_t base = 0;
@@ -852,22 +1096,36 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
-        // the candidate tiles, dealt to the waves; the next candidate's data is in flight while one is matched
+        // the candidate tiles, dealt to the waves; two candidates' data are in flight while one is matched
         uint32_t j = wib;
-        uint2 item = j < n ? s_list[j] : make_uint2(0u, 0u);
-        TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
+        uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
+        uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
+        TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
+        TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
         while (j < n) {
-            const uint2 cur = item;
-            const TileRegs r = nxt;
+            const uint2 cur = it0;
+            const TileRegs r = q0;
+            it0 = it1;
+            q0 = q1;
             j += WPB;
-            if (j < n) {
-                item = s_list[j];
-                nxt = load_tile(P.tiles, item.x, item.y, lane);
+            if (j + WPB < n) {
+                it1 = s_list[j + WPB];
+                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
             }
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            if (do_inline) {
+                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
+                const unsigned long long holders = __ballot(mine != 0);
+                const int lane_s = __ffsll((long long)holders) - 1;
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s);
+                if (__popcll(holders) == 1 && __popc(mm_s) == 1) {
+                    single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                    continue;
+                }
+            }
             if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
         }
         __syncthreads();
@@ -878,6 +1136,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         P.work_cnt[blockIdx.x] = s_hits;
         if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
     }
+    if (INLINE) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
 }
 
 // ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
@@ -935,7 +1194,8 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     const uint32_t total = s_pref[MAX_LISTS];
     if (blockIdx.x * WPB >= total) return; // nothing for this workgroup (uniform)
 
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane};
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b);
     agg_init(C.agg);
@@ -971,6 +1231,110 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
         const uint32_t nb = next_lane(r.vb.x, PADPAD);
         slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
     }
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+}
+
+// ---------------------------------------------------------------- split form fused again on top of the skip index
+// k_apply_skip = k_scan_skip + the rewrite, in one launch: once the signatures have removed most tiles from the scan,
+// a second kernel (worklist, prefix, re-read of the tiles) costs more than it saves.  Stragglers are handled by
+// dynamic scheduling instead: workgroups draw chunks of SCAN_CHUNK consecutive tiles from 8 sharded queue heads in
+// DevState (reset by k_select), and inside a chunk the waves draw candidate tiles from an LDS counter.
+struct ApplySkipParams {
+    ApplyParams A;
+    uint32_t n_chunks;
+    unsigned long long *blk_read; // [gridDim.x] candidate tiles read (statistics)
+};
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK, 6) void k_apply_skip(ApplySkipParams Q) {
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
+    __shared__ unsigned long long s_cnt[2];
+    __shared__ uint2 s_list[SCAN_CHUNK];
+    __shared__ uint32_t s_n, s_take, s_chunk;
+
+    const ApplyParams &P = Q.A;
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b);
+    const uint32_t mk = C.mk;
+    const uint32_t ha = sig_bit(C.a), hb = sig_bit(C.b), hp = pair_bit(C.self);
+    const uint32_t *sa = P.sig + (size_t)(ha >> 5) * P.sig_stride;
+    const uint32_t *sb = P.sig + (size_t)(hb >> 5) * P.sig_stride;
+    const uint32_t *sp = P.sig + (size_t)(TOK_WORDS + (hp >> 5)) * P.sig_stride;
+    agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    WaveLds &W = s_w[wib];
+    wave_lds_init(W, lane);
+    const uint32_t nq = min(8u, gridDim.x);  // queue shards in use (every shard needs at least one workgroup)
+    const uint32_t q = blockIdx.x % nq;      // this workgroup's shard: chunks q, q + nq, q + 2 nq, ...
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        s_take = 0;
+        s_chunk = atomicAdd(&st->chunk_next[q], 1u) * nq + q;
+    }
+    __syncthreads();
+
+    unsigned long long wave_sites = 0, wave_freed = 0, n_read = 0;
+    while (true) {
+        const uint32_t ch = s_chunk; // uniform
+        if (ch >= Q.n_chunks) break;
+        // ---- one thread per tile: signature test (16 B per tile)
+        const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
+        uint32_t len = 0;
+        bool maybe = false;
+        if (t < P.n_tiles) {
+            len = P.tile_len[t];
+            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & (sp[t] >> (hp & 31)) & 1u);
+        }
+        const unsigned long long m = __ballot(maybe);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (maybe) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(t, len);
+        __syncthreads();
+        const uint32_t n = s_n;
+        n_read += n;
+        if (threadIdx.x == 0) s_chunk = atomicAdd(&st->chunk_next[q], 1u) * nq + q; // next chunk id arrives meanwhile
+        // ---- candidates: waves draw them one at a time; matched tiles are rewritten on the spot
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(&s_take, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        uint2 item = j < n ? s_list[j] : make_uint2(0u, 0u);
+        TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
+        while (j < n) {
+            const uint2 cur = item;
+            const TileRegs r = nxt;
+            if (lane == 0) j = atomicAdd(&s_take, 1u);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j < n) {
+                item = s_list[j];
+                nxt = load_tile(P.tiles, item.x, item.y, lane);
+            }
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_take = 0;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
+#ifdef YB_PROFILE_SLOW
+    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
+#endif
     apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
 }
 
@@ -1225,6 +1589,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         // no replica can run out of probes on its own.
         if (st->halt == 0 && st->table_entries * 4ull > ((unsigned long long)P.table.mask + 1ull) * 3ull) st->halt = HALT_TABLE_FULL;
         if (P.delta_hdr) P.delta_hdr->count = 0ull;
+        for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
         s_flag = st->done | st->halt;
     }
     __syncthreads();

@@ -67,7 +67,7 @@ def lib() -> ctypes.CDLL:
         L.yabpe_token_bytes.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_uint32)]
         L.yabpe_stats.argtypes = [c_void_p, POINTER(Stats)]
         L.yabpe_iter_log.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
-        L.yabpe_event_log.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
+        L.yabpe_event_log.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]
         L.yabpe_verify_table.argtypes = [c_void_p, POINTER(c_uint64)]
         L.yabpe_stream_checksum.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_generate.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32, c_int,
@@ -193,11 +193,12 @@ class Context:
 
     def event_log(self):
         n = c_uint32(0)
-        self._chk(lib().yabpe_event_log(self._h, None, None, 0, byref(n)))
+        self._chk(lib().yabpe_event_log(self._h, None, None, None, 0, byref(n)))
         it = np.zeros(max(n.value, 1), dtype=np.uint32)
         us = np.zeros(max(n.value, 1), dtype=np.float32)
-        self._chk(lib().yabpe_event_log(self._h, it.ctypes.data, us.ctypes.data, n.value, byref(n)))
-        return it[:n.value], us[:n.value]
+        scan = np.zeros(max(n.value, 1), dtype=np.float32)
+        self._chk(lib().yabpe_event_log(self._h, it.ctypes.data, us.ctypes.data, scan.ctypes.data, n.value, byref(n)))
+        return it[:n.value], us[:n.value], scan[:n.value]
 
     def verify_table(self) -> int:
         m = c_uint64(0)
