@@ -8,7 +8,7 @@ OUT=gpurun_out/pmc
 rm -rf $OUT && mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-include-regex "k_scan" --output-format csv -d $OUT/$C -- \
-    python3 bench.py --no-cpu-baseline --no-dedup-line --event-sample 1 "$@" > $OUT/bench_$C.json 2> $OUT/$C.err
+    python3 bench.py --no-cpu-baseline --no-dedup-line --merges 2500 --roofline-merges 2500 "$@" > $OUT/bench_$C.json 2> $OUT/$C.err
 done
 python3 - <<'PY'
 import csv, glob, json
@@ -16,7 +16,7 @@ def load(c):
     f = glob.glob(f"gpurun_out/pmc/{c}/*/*counter_collection.csv")[0]
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("yb::k_scan(") and r["Counter_Name"] == c]
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
-rf = json.load(open("gpurun_out/pmc/bench_FETCH_SIZE.json"))["roofline"]
+rf = json.load(open("gpurun_out/pmc/bench_FETCH_SIZE.json"))["roofline"]  # k_scan of the auxiliary pass
 mf, mw = sum(f) / len(f), sum(w) / len(w)
 traffic = 2 * mf * 1024 + mw * 1024
 out = {"kernel": "yb::k_scan", "dispatches": len(f), "mean_FETCH_SIZE_KiB": mf, "mean_WRITE_SIZE_KiB": mw,

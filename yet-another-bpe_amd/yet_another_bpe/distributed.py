@@ -147,9 +147,13 @@ class ShardedRunner:
             attach(self._ctx, self.rank, self.world, self.transport)
         return self._ctx
 
-    def run(self, num_merges: int, min_frequency: int, dedup: bool = False, event_sample: int = 0) -> dict:
+    def run(self, num_merges: int, min_frequency: int, dedup: bool = False, event_sample: int = 0,
+            options: dict | None = None) -> dict:
         ctx = self._context()
         ctx.set_option("event_sample", event_sample)
+        ctx.set_option("skip_index", 1)
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
         ctx.set_vocab(self.base)  # resets tokens / merge state; the communicator stays attached
         ctx.load_words_ptr(self.bytes_ptr, self.off_ptr + 8 * self.w0, self.w1 - self.w0, dedup=dedup)
         left, right, merged, count = ctx.train(num_merges, min_frequency)
