@@ -264,7 +264,7 @@ void table_free(PairTable &t) {
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
     TRY(dmalloc(c, &t.keys, cap));
     TRY(dmalloc(c, &t.cnt, cap));
-    t.mask = (uint32_t)(cap - 1);
+    t.cap = (uint32_t)cap;
     t.max_probe = (uint32_t)std::min<uint64_t>(cap, 2048);
     t.entries = entries_ctr;
     HIPCHK(c, hipMemsetAsync(t.keys, 0xFF, cap * sizeof(uint32_t), c->stream));
@@ -426,7 +426,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
     if (!c->multi) return launch_count_local(c, t);
     // generic multi-GPU count: local table -> records -> all-gather -> sum into t
     PairTable lt{};
-    const uint64_t lcap = (uint64_t)t.mask + 1;
+    const uint64_t lcap = (uint64_t)t.cap;
     HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
     TRY(table_alloc(c, lt, lcap, &c->scratch64[9]));
     TRY(launch_count_local(c, lt));
@@ -438,6 +438,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
 // (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
 int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
+    bool shrunk = false;
     for (int attempt = 0; attempt < 16; ++attempt) {
         table_free(c->table);
         HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
@@ -449,6 +450,13 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
         unsigned long long bad = (c->st_host->halt_req != 0 || c->st_host->table_entries * 2 > cap) ? 1 : 0, any_bad = 0;
         TRY(comm_max(c, bad, &any_bad));  // replicas differ in layout: all ranks retry together
         if (!any_bad) {
+            if (!shrunk && c->st_host->table_entries * 8 < cap && cap > (1ull << 16)) {
+                // far too roomy (the argmax reads every slot each merge): count once more at ~2x the entries
+                // (the entry count is the same on every rank, so all ranks take this branch together)
+                shrunk = true;
+                cap = std::max<uint64_t>(c->st_host->table_entries * 2, 1ull << 16);
+                continue;
+            }
             c->stats.table_rebuilds++;
             return 0;
         }
@@ -460,7 +468,7 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
 
 // Grow the pair table by re-inserting its live entries (entries whose count fell to 0 are dropped).
 int table_grow(yabpe_ctx *c, uint64_t new_cap) {
-    for (int attempt = 0; attempt < 8; ++attempt, new_cap *= 2) {
+    for (int attempt = 0; attempt < 8; ++attempt, new_cap = new_cap * 3 / 2) {
         PairTable nt{};
         HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
         TRY(table_alloc(c, nt, new_cap, &c->st->table_entries));
@@ -469,7 +477,7 @@ int table_grow(yabpe_ctx *c, uint64_t new_cap) {
         hipLaunchKernelGGL(k_rehash, dim3(grid), dim3(BLOCK), 0, c->stream, R);
         HIPCHK(c, hipGetLastError());
         TRY(state_pull(c));
-        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 2 <= new_cap) {
+        if (c->st_host->halt_req == 0 && c->st_host->table_entries * 10 <= new_cap * 6) {
             table_free(c->table);
             c->table = nt;
             c->table_cap = new_cap;
@@ -943,7 +951,10 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                    c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u)};
     hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
-    hipLaunchKernelGGL(k_rank_update, dim3(cdiv64(tokens_upper, BLOCK)), dim3(BLOCK), 0, c->stream, R);
+    const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
+    // lexrank maintenance rides on the k_scan_skip launch when that form is used (one dependent launch fewer)
+    const bool rank_rides = c->n_tiles && c->split_mode && c->sig && c->sig_valid && !optv(c, "fuse_skip", 0) && optv(c, "rank_rides", 1);
+    if (!rank_rides) hipLaunchKernelGGL(k_rank_update, dim3(rank_blocks), dim3(BLOCK), 0, c->stream, R);
     const PairTable out_table = c->multi ? c->delta : c->table;
     if (ev) {
         ev->split = c->split_mode;
@@ -983,12 +994,14 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 scan_grid = std::max(1u, std::min<uint32_t>(n_chunks, MAX_LISTS));
                 seg = SCAN_CHUNK * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
-                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read};
+                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
+                                  scan_grid, R};
                 c->blk_used = std::max(c->blk_used, scan_grid);
+                const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
                 if (!c->weighted && optv(c, "inline_single", 1))
-                    hipLaunchKernelGGL(k_scan_skip<true>, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
+                    hipLaunchKernelGGL(k_scan_skip<true>, dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
                 else
-                    hipLaunchKernelGGL(k_scan_skip<false>, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SQ);
+                    hipLaunchKernelGGL(k_scan_skip<false>, dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
                 c->scan_skip_launches++;
             } else {
                 scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 4)), MAX_LISTS));
@@ -1018,7 +1031,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     if (c->multi) {
         // this rank's aggregated deltas -> [header | records]; one all-gather; every rank applies all of them
         ExtractParams X{c->delta, reinterpret_cast<DeltaHdr *>(c->xsend), reinterpret_cast<DeltaRec *>(c->xsend + 16), c->xcap, c->st};
-        hipLaunchKernelGGL(k_delta_extract, dim3((uint32_t)std::max<uint64_t>(1, ((uint64_t)c->delta.mask + 1) / BLOCK / 4)), dim3(BLOCK), 0, c->stream, X);
+        hipLaunchKernelGGL(k_delta_extract, dim3((uint32_t)std::max<uint64_t>(1, (uint64_t)c->delta.cap / BLOCK / 4)), dim3(BLOCK), 0, c->stream, X);
         TRY(comm_allgather(c, c->xsend, c->xrecv, c->xstride));
         DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xcap, c->xstride, c->table, c->st};
         hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xcap, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
@@ -1157,7 +1170,8 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             break;
         }
         // housekeeping between batches
-        if (h->table_entries * 2 > c->table_cap) TRY(table_grow(c, c->table_cap * 2));  // same decision on every rank
+        if (h->table_entries * 10 > c->table_cap * 7)  // > 70 % full; same decision on every rank
+            TRY(table_grow(c, std::max<uint64_t>(h->table_entries * 2, 1ull << 16)));
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
             TRY(retile_flat(c));

@@ -63,10 +63,15 @@ struct DevState {
 struct PairTable {
     uint32_t *keys;
     unsigned long long *cnt;
-    uint32_t mask;
+    uint32_t cap;       // any size >= 2 (not only powers of two: the argmax scan reads every slot, so the table is kept small)
     uint32_t max_probe;
     unsigned long long *entries; // where successful inserts are counted
 };
+__device__ __forceinline__ uint32_t hash32(uint32_t k);
+__device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
+    return (uint32_t)(((unsigned long long)hash32(key) * t.cap) >> 32);
+}
+__device__ __forceinline__ uint32_t pt_next(const PairTable &t, uint32_t s) { return s + 1 == t.cap ? 0u : s + 1; }
 
 struct Best {
     unsigned long long cnt;
@@ -127,7 +132,7 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 
 // ---------------------------------------------------------------- global pair table
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d) {
-    uint32_t s = hash32(key) & t.mask;
+    uint32_t s = pt_home(t, key);
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
         uint32_t k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == EMPTY) {
@@ -141,7 +146,7 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
             atomicAdd(&t.cnt[s], (unsigned long long)d);
             return;
         }
-        s = (s + 1) & t.mask;
+        s = pt_next(t, s);
     }
     atomicMax(&st->halt_req, (uint32_t)HALT_TABLE_FULL);
 }
@@ -987,6 +992,75 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
     if (threadIdx.x == 0) P.work_cnt[blockIdx.x] = s_n;
 }
 
+// ---------------------------------------------------------------- token byte strings on the device
+struct TokTable {
+    uint8_t *pool;
+    uint32_t *off;
+    uint32_t *len;
+    uint32_t *rank;  // lexrank[id]
+    uint32_t *vset;  // open-addressing set of ids keyed by the token bytes
+    uint32_t vset_mask;
+    uint32_t pool_cap;
+};
+
+// Hash of a byte string from its length and its first/last <= 16 bytes (cheap for very long tokens;
+// equality is always decided by a full compare).  Must be identical on host and device.
+YB_HD uint32_t yb_tok_hash(const uint8_t *p, uint32_t n) {
+    uint32_t h = 2166136261u ^ n;
+    uint32_t m = n < 16u ? n : 16u;
+    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[i]) * 16777619u;
+    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[n - 1 - i]) * 16777619u;
+    h ^= h >> 15;
+    h *= 0x2c1b3c6dU;
+    h ^= h >> 12;
+    return h;
+}
+
+// Python bytes order: unsigned bytewise, a proper prefix sorts lower.
+__device__ __forceinline__ int tok_cmp(const TokTable &tt, uint32_t x, uint32_t y) {
+    const uint8_t *px = tt.pool + tt.off[x], *py = tt.pool + tt.off[y];
+    const uint32_t lx = tt.len[x], ly = tt.len[y];
+    const uint32_t n = lx < ly ? lx : ly;
+    for (uint32_t i = 0; i < n; ++i) {
+        int d = (int)px[i] - (int)py[i];
+        if (d) return d;
+    }
+    return (lx > ly) - (lx < ly);
+}
+
+// lexrank maintenance after a new token c was created: tokens above it move up by one, and c's rank is the
+// number of tokens below it.
+struct RankParams {
+    TokTable tt;
+    DevState *st;
+};
+
+__device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t block) {
+    __shared__ uint32_t s_less;
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    if (!st->c_is_new) return;
+    const uint32_t n = st->n_tokens, c = st->c;
+    if (block * BLOCK >= n) return;
+    if (threadIdx.x == 0) s_less = 0;
+    __syncthreads();
+    const uint32_t t = block * BLOCK + threadIdx.x;
+    int less = 0;
+    if (t < n && t != c) {
+        int cmp = tok_cmp(P.tt, t, c);
+        if (cmp > 0)
+            P.tt.rank[t] += 1;
+        else
+            less = 1;
+    }
+    unsigned long long m = __ballot(less);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_less, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_less) atomicAdd(&P.tt.rank[c], s_less);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) { rank_update_block(P, blockIdx.x); }
+
 // ---------------------------------------------------------------- skip index: signatures and the scan that uses them
 struct SigParams {
     const uint16_t *tiles;
@@ -1042,7 +1116,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
 struct ScanSkipParams {
     ScanParams S;
     ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
-    unsigned long long *blk_read; // [gridDim.x] tiles actually read (statistics; plain stores)
+    unsigned long long *blk_read; // [scan_blocks] tiles actually read (statistics; plain stores)
+    uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
+    RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
 };
 
 // INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
@@ -1056,7 +1132,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     __shared__ unsigned long long s_cnt[2];
     const ScanParams &P = Q.S;
     DevState *st = P.st;
+    if (blockIdx.x >= Q.scan_blocks) {
+        rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
+        return;
+    }
     if (st->done | st->halt) return;
+    const uint32_t n_blocks = Q.scan_blocks;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SlowCtx<int> C{Q.A, Agg<int>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
@@ -1080,7 +1161,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t n_chunks = (P.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
         const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
         uint32_t len = 0;
         bool maybe = false;
@@ -1096,21 +1177,25 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
-        // the candidate tiles, dealt to the waves; two candidates' data are in flight while one is matched
+        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched
         uint32_t j = wib;
         uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
         uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
+        uint2 it2 = j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
         TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
         TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
+        TileRegs q2 = load_tile(P.tiles, it2.x, it2.y, lane);
         while (j < n) {
             const uint2 cur = it0;
             const TileRegs r = q0;
             it0 = it1;
             q0 = q1;
+            it1 = it2;
+            q1 = q2;
             j += WPB;
-            if (j + WPB < n) {
-                it1 = s_list[j + WPB];
-                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
+            if (j + 2 * WPB < n) {
+                it2 = s_list[j + 2 * WPB];
+                q2 = load_tile(P.tiles, it2.x, it2.y, lane);
             }
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
@@ -1469,7 +1554,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_partial(ArgmaxParams P) {
     __shared__ Best s_b[WPB];
     if (P.st->done | P.st->halt) return;
     Best best{0ull, 0u, EMPTY, 0u, 0u};
-    const uint32_t cap = P.table.mask + 1;
+    const uint32_t cap = P.table.cap;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
         const long long cn = (long long)P.table.cnt[s]; // empty slots hold 0: the key is read for candidates only
         if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
@@ -1487,42 +1572,6 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_partial(ArgmaxParams P) {
             if (best_gt(s_b[i], best)) best = s_b[i];
         P.partials[blockIdx.x] = best;
     }
-}
-
-// ---------------------------------------------------------------- token byte strings on the device
-struct TokTable {
-    uint8_t *pool;
-    uint32_t *off;
-    uint32_t *len;
-    uint32_t *rank;  // lexrank[id]
-    uint32_t *vset;  // open-addressing set of ids keyed by the token bytes
-    uint32_t vset_mask;
-    uint32_t pool_cap;
-};
-
-// Hash of a byte string from its length and its first/last <= 16 bytes (cheap for very long tokens;
-// equality is always decided by a full compare).  Must be identical on host and device.
-YB_HD uint32_t yb_tok_hash(const uint8_t *p, uint32_t n) {
-    uint32_t h = 2166136261u ^ n;
-    uint32_t m = n < 16u ? n : 16u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[i]) * 16777619u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[n - 1 - i]) * 16777619u;
-    h ^= h >> 15;
-    h *= 0x2c1b3c6dU;
-    h ^= h >> 12;
-    return h;
-}
-
-// Python bytes order: unsigned bytewise, a proper prefix sorts lower.
-__device__ __forceinline__ int tok_cmp(const TokTable &tt, uint32_t x, uint32_t y) {
-    const uint8_t *px = tt.pool + tt.off[x], *py = tt.pool + tt.off[y];
-    const uint32_t lx = tt.len[x], ly = tt.len[y];
-    const uint32_t n = lx < ly ? lx : ly;
-    for (uint32_t i = 0; i < n; ++i) {
-        int d = (int)px[i] - (int)py[i];
-        if (d) return d;
-    }
-    return (lx > ly) - (lx < ly);
 }
 
 struct SelectParams {
@@ -1587,7 +1636,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         if (st->halt == 0 && st->halt_req != 0) st->halt = st->halt_req;
         // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
         // no replica can run out of probes on its own.
-        if (st->halt == 0 && st->table_entries * 4ull > ((unsigned long long)P.table.mask + 1ull) * 3ull) st->halt = HALT_TABLE_FULL;
+        if (st->halt == 0 && st->table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) st->halt = HALT_TABLE_FULL; // > 80 % full
         if (P.delta_hdr) P.delta_hdr->count = 0ull;
         for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
         s_flag = st->done | st->halt;
@@ -1704,37 +1753,6 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
     }
 }
 
-// lexrank maintenance after a new token c was created: tokens above it move up by one, and c's rank is the
-// number of tokens below it.
-struct RankParams {
-    TokTable tt;
-    DevState *st;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) {
-    __shared__ uint32_t s_less;
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    if (!st->c_is_new) return;
-    const uint32_t n = st->n_tokens, c = st->c;
-    if (blockIdx.x * BLOCK >= n) return;
-    if (threadIdx.x == 0) s_less = 0;
-    __syncthreads();
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    int less = 0;
-    if (t < n && t != c) {
-        int cmp = tok_cmp(P.tt, t, c);
-        if (cmp > 0)
-            P.tt.rank[t] += 1;
-        else
-            less = 1;
-    }
-    unsigned long long m = __ballot(less);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_less, (uint32_t)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_less) atomicAdd(&P.tt.rank[c], s_less);
-}
-
 // ================================================================ loading words into tiles
 struct LoadParams {
     const uint8_t *bytes;
@@ -1842,7 +1860,7 @@ struct RehashParams {
     DevState *st;
 };
 __global__ __launch_bounds__(BLOCK) void k_rehash(RehashParams P) {
-    const uint32_t cap = P.from.mask + 1;
+    const uint32_t cap = P.from.cap;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
         const uint32_t k = P.from.keys[s];
         if (k == EMPTY) continue;
@@ -1866,7 +1884,7 @@ struct ExtractParams {
     DevState *st;
 };
 __global__ __launch_bounds__(BLOCK) void k_delta_extract(ExtractParams P) {
-    const uint32_t slots = P.dt.mask + 1;
+    const uint32_t slots = P.dt.cap;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < slots; s += gridDim.x * BLOCK) {
         const uint32_t k = P.dt.keys[s];
         if (k == EMPTY) continue;
@@ -1924,7 +1942,7 @@ struct DumpParams {
     unsigned long long cap;
 };
 __global__ __launch_bounds__(BLOCK) void k_table_dump(DumpParams P) {
-    const uint32_t slots = P.t.mask + 1;
+    const uint32_t slots = P.t.cap;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < slots; s += gridDim.x * BLOCK) {
         const uint32_t k = P.t.keys[s];
         if (k == EMPTY) continue;
@@ -1952,18 +1970,18 @@ struct CmpParams {
 };
 
 __device__ __forceinline__ long long gt_lookup(const PairTable &t, uint32_t key) {
-    uint32_t s = hash32(key) & t.mask;
-    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    uint32_t s = pt_home(t, key);
+    for (uint32_t probe = 0; probe < t.cap; ++probe) {
         uint32_t k = t.keys[s];
         if (k == key) return (long long)t.cnt[s];
         if (k == EMPTY) return 0;
-        s = (s + 1) & t.mask;
+        s = pt_next(t, s);
     }
     return 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_table_compare(CmpParams P) {
-    const uint32_t cap = P.ta.mask + 1;
+    const uint32_t cap = P.ta.cap;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
         uint32_t k = P.ta.keys[s];
         if (k == EMPTY) continue;
