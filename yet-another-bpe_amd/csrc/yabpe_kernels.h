@@ -1125,8 +1125,9 @@ struct ScanSkipParams {
 // (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
 template <bool INLINE>
 __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
-    __shared__ uint32_t s_n, s_hits;
+    __shared__ uint32_t s_n, s_hits, s_nrew;
     __shared__ uint2 s_list[SCAN_CHUNK];
+    __shared__ uint2 s_rew[INLINE ? SCAN_CHUNK : 1];
     __shared__ uint32_t s_keys[INLINE ? AGG_N : 1];
     __shared__ int s_vals[INLINE ? AGG_N : 1];
     __shared__ unsigned long long s_cnt[2];
@@ -1156,6 +1157,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     if (threadIdx.x == 0) {
         s_n = 0;
         s_hits = 0;
+        s_nrew = 0;
     }
     __syncthreads();
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
@@ -1201,20 +1203,52 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            // A rewrite stores to HBM, and on gfx950 stores queue in the same in-order vmcnt as this wave's prefetched
+            // loads: rewriting here would stall the scan behind every store.  Matched tiles are only noted; they are
+            // rewritten after the candidate loop, when no load of this wave is waiting behind the stores.
             if (do_inline) {
+                if (lane == 0) s_rew[atomicAdd(&s_nrew, 1u)] = cur;
+            } else {
+                if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
+            }
+        }
+        __syncthreads();
+        if (do_inline) {
+            const uint32_t nr = s_nrew;
+            uint32_t k = wib;
+            uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
+            uint2 w1 = k + WPB < nr ? s_rew[k + WPB] : make_uint2(0u, 0u);
+            TileRegs t0 = load_tile(P.tiles, w0.x, w0.y, lane); // L2 hits: the tile was read a moment ago
+            TileRegs t1 = load_tile(P.tiles, w1.x, w1.y, lane);
+            while (k < nr) {
+                const uint2 cur = w0;
+                const TileRegs r = t0;
+                w0 = w1;
+                t0 = t1;
+                k += WPB;
+                if (k + WPB < nr) {
+                    w1 = s_rew[k + WPB];
+                    t1 = load_tile(P.tiles, w1.x, w1.y, lane);
+                }
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+                const uint32_t na = next_lane(r.va.x, b0);
+                const uint32_t nb = next_lane(r.vb.x, PADPAD);
                 const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
                 const unsigned long long holders = __ballot(mine != 0);
                 const int lane_s = __ffsll((long long)holders) - 1;
-                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s);
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
                 if (__popcll(holders) == 1 && __popc(mm_s) == 1) {
                     single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
-                    continue;
+                } else if (lane == 0) {
+                    my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
                 }
             }
-            if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_nrew = 0;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
