@@ -73,6 +73,7 @@ Rccl *rccl() {
 }
 
 constexpr uint32_t MAX_APPLY_BLOCKS = 8192;
+constexpr uint32_t DENSE_CAP = 4096;  // dense worklist entries (sparse merges)
 thread_local std::string g_create_error;
 
 struct EventPair {
@@ -138,6 +139,7 @@ struct yabpe_ctx {
     // split apply: worklist of tiles that contain the pair
     uint2 *work = nullptr;
     uint32_t *work_cnt = nullptr;
+    uint2 *work_dense = nullptr;  // sparse merges: one list for all workgroups
     uint64_t work_cap = 0;
     bool split_mode = false;
     std::vector<float> ev_scan_us;
@@ -148,6 +150,7 @@ struct yabpe_ctx {
     uint64_t scan_skip_launches = 0;
     bool sig_valid = false;
     uint32_t sig_built_at = 0;
+    bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
     // multi-GPU
     int rank = 0, n_ranks = 1;
     bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
@@ -668,6 +671,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->blk_stats);
     dfree(c->work);
     dfree(c->work_cnt);
+    dfree(c->work_dense);
     dfree(c->blk_read);
     table_free(c->delta);
     dfree(c->xsend);
@@ -939,6 +943,7 @@ static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
         HIPCHK(c, hipMemsetAsync(c->work_cnt, 0, MAX_LISTS * 4, c->stream));
         TRY(dmalloc(c, &c->blk_read, MAX_LISTS));
         HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
+        TRY(dmalloc(c, &c->work_dense, DENSE_CAP));
     }
     return 0;
 }
@@ -995,7 +1000,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 seg = SCAN_CHUNK * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
-                                  scan_grid, R};
+                                  scan_grid, c->dense_mode ? c->work_dense : nullptr, DENSE_CAP, R};
                 c->blk_used = std::max(c->blk_used, scan_grid);
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
                 if (!c->weighted && optv(c, "inline_single", 1))
@@ -1011,9 +1016,11 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
             }
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
-            const uint32_t slow_grid = std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
+            const bool dense = use_sig && c->dense_mode;
+            const uint32_t slow_grid = dense ? std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks_dense", 128)))
+                                             : std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
             c->blk_used = std::max(c->blk_used, slow_grid);
-            SlowParams SL{P, c->work, c->work_cnt, scan_grid, seg};
+            SlowParams SL{P, c->work, c->work_cnt, scan_grid, seg, dense ? c->work_dense : nullptr, DENSE_CAP};
             if (c->weighted)
                 hipLaunchKernelGGL(k_slow<true>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
             else
@@ -1067,6 +1074,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     c->ev_scan_us.clear();
     c->split_mode = false;
     c->sig_valid = false;
+    c->dense_mode = false;
     if (num_merges == 0) return YABPE_OK;
 
     if (c->rec_cap < num_merges) {
@@ -1113,6 +1121,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->split_mode = split_opt == 1;
         else if (!c->split_mode && h->iter > rec_base && h->best_count * 2 < c->n_tiles)
             c->split_mode = true;
+        {
+            const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
+            const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
+            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < 256.0);
+        }
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
             const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 4096));

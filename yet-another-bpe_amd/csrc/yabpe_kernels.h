@@ -58,6 +58,8 @@ struct DevState {
     unsigned long long delta_entries;
     unsigned long long best_count; // count of the merge being applied
     uint32_t chunk_next[8];        // k_apply_skip: dynamic chunk queues (sharded 8 ways), reset by k_select
+    uint32_t work_total;           // dense worklist: items appended by k_scan_skip this merge (reset by k_select)
+    uint32_t pad1;
 };
 
 struct PairTable {
@@ -1118,6 +1120,8 @@ struct ScanSkipParams {
     ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
     unsigned long long *blk_read; // [scan_blocks] tiles actually read (statistics; plain stores)
     uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
+    uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
+    uint32_t dense_cap;
     RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
 };
 
@@ -1251,6 +1255,17 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         }
         __syncthreads();
     }
+    if (Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
+        __shared__ uint32_t s_base;
+        __syncthreads();
+        const uint32_t nh = s_hits;
+        if (nh) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&st->work_total, nh);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nh; i += BLOCK)
+                if (s_base + i < Q.dense_cap) Q.dense[s_base + i] = my_work[i];
+        }
+    }
     if (threadIdx.x == 0) {
         P.work_cnt[blockIdx.x] = s_hits;
         if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
@@ -1265,6 +1280,8 @@ struct SlowParams {
     const uint32_t *work_cnt;
     uint32_t n_lists; // grid of k_scan
     uint32_t seg;
+    const uint2 *dense; // != NULL: items are dense[0 .. st->work_total) (sparse merges); falls back to the lists on overflow
+    uint32_t dense_cap;
 };
 constexpr int MAX_LISTS = 2048;
 
@@ -1283,6 +1300,12 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     if (st->done | st->halt) return;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t total;
+    const bool dense = S.dense != nullptr && st->work_total <= S.dense_cap; // uniform over the grid
+    if (dense) {
+        total = st->work_total;
+        if (blockIdx.x * WPB >= total) return; // usually: nothing, or a handful of tiles
+    } else {
     // exclusive prefix over the per-workgroup list lengths (every workgroup computes the same small scan)
     constexpr int PER = MAX_LISTS / BLOCK;
     uint32_t v[PER], tsum = 0;
@@ -1310,8 +1333,9 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     }
     if (threadIdx.x == BLOCK - 1) s_pref[MAX_LISTS] = run;
     __syncthreads();
-    const uint32_t total = s_pref[MAX_LISTS];
+    total = s_pref[MAX_LISTS];
     if (blockIdx.x * WPB >= total) return; // nothing for this workgroup (uniform)
+    }
 
     SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
@@ -1326,6 +1350,7 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     const uint32_t n_waves = gridDim.x * WPB;
     // item g -> (tile, len): find the list that holds it (last l with s_pref[l] <= g)
     auto fetch = [&](uint32_t g) -> uint2 {
+        if (dense) return S.dense[g];
         uint32_t lo = 0, hi = S.n_lists;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -1673,6 +1698,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         if (st->halt == 0 && st->table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) st->halt = HALT_TABLE_FULL; // > 80 % full
         if (P.delta_hdr) P.delta_hdr->count = 0ull;
         for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
+        st->work_total = 0u;
         s_flag = st->done | st->halt;
     }
     __syncthreads();
