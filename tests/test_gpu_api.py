@@ -112,3 +112,39 @@ def test_train_bpe_speed(golden_dir):
     t0 = time.time()
     run_train_bpe(golden_dir / "corpus.en", 500, ["<|endoftext|>"])
     assert time.time() - t0 < 1.5
+
+
+class TestTrainIntegration:
+    """reference tests/test_trainer.py:354-604 (train()/save() integration), restated."""
+
+    def test_train_multiple_files_and_attributes(self):
+        trainer = BBPETrainer(BBPETrainerConfig(vocab_size=300, min_frequency=2, max_workers=2))
+        model = trainer.train([DATA / "sample.txt", DATA / "multiline.txt", str(DATA / "simple.txt")])
+        assert isinstance(model.vocab, dict) and isinstance(model.merges, list) and isinstance(model.special_tokens, list)
+        assert all(isinstance(k, bytes) and isinstance(v, int) for k, v in model.vocab.items())
+        assert sorted(model.vocab.values()) == list(range(len(model.vocab)))  # ids are contiguous
+        assert len(model.vocab) == 260 + len(model.merges)
+        for a, b in model.merges:
+            assert a + b in model.vocab
+        model.vocab[b"zzz"] = -1  # BBPEModel holds copies (trainer.py:50-52)
+        assert b"zzz" not in trainer._vocab
+
+    def test_worker_count_and_chunking_do_not_change_the_model(self):
+        a = BBPETrainer(BBPETrainerConfig(vocab_size=290, min_frequency=1, max_workers=1)).train([DATA / "sample.txt"])
+        b = BBPETrainer(BBPETrainerConfig(vocab_size=290, min_frequency=1, max_workers=4, chunk_size_bytes=1 << 20)).train([DATA / "sample.txt"])
+        assert a.merges == b.merges and a.vocab == b.vocab
+
+    def test_save_writes_the_three_files(self, tmp_path):
+        trainer = BBPETrainer(BBPETrainerConfig(vocab_size=280, min_frequency=1, max_workers=1))
+        trainer.train([DATA / "sample.txt"])
+        trainer.save(str(tmp_path / "out" / "nested"))
+        for name in ("vocab.json", "merges.txt", "special_tokens.json"):
+            assert (tmp_path / "out" / "nested" / name).exists()
+        assert len((tmp_path / "out" / "nested" / "merges.txt").read_text(encoding="utf-8").splitlines()) >= 1
+
+    def test_unicode_corpus(self):
+        model = BBPETrainer(BBPETrainerConfig(vocab_size=275, min_frequency=1, max_workers=1)).train([DATA / "unicode.txt"])
+        from oracle import oracle as _o
+        t = BBPETrainer(BBPETrainerConfig(vocab_size=275, min_frequency=1, max_workers=1))
+        words = [bytes(s) for s in t._preprocess_corpus([DATA / "unicode.txt"])]
+        assert model.merges == _o.merge_loop(words, 275, 1, ["[PAD]", "[UNK]", "[BOS]", "[EOS]"])[1]

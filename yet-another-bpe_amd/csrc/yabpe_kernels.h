@@ -36,6 +36,7 @@ constexpr int TOK_WORDS = 64;        // tile signature, part 1: 2,048-bit set of
 constexpr int PAIR_WORDS = 128;      // part 2: 4,096-bit set of the adjacent pairs present in the tile
 constexpr int SIG_WORDS = TOK_WORDS + PAIR_WORDS;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time
+constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4 };
 
@@ -959,6 +960,8 @@ struct ScanParams {
 
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
     __shared__ uint32_t s_n;
+    __shared__ uint2 s_hl[SCAN_HITS_LDS]; // hits are buffered here: a store inside the loop would queue in front of the
+                                          // wave's prefetched loads (stores and loads share the in-order vmcnt)
     DevState *st = P.st;
     if (st->done | st->halt) return;
     const uint32_t mk = yb_memkey(st->a, st->b);
@@ -987,10 +990,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            if (lane == 0) my_work[atomicAdd(&s_n, 1u)] = make_uint2(tile, len);
+            if (lane == 0) {
+                const uint32_t idx = atomicAdd(&s_n, 1u);
+                if (idx < (uint32_t)SCAN_HITS_LDS)
+                    s_hl[idx] = make_uint2(tile, len);
+                else
+                    my_work[idx] = make_uint2(tile, len);
+            }
         }
     }
     __syncthreads();
+    const uint32_t nh = min(s_n, (uint32_t)SCAN_HITS_LDS);
+    for (uint32_t i = threadIdx.x; i < nh; i += BLOCK) my_work[i] = s_hl[i];
     if (threadIdx.x == 0) P.work_cnt[blockIdx.x] = s_n;
 }
 
