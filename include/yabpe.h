@@ -112,6 +112,9 @@ typedef struct yabpe_stats_t {
     /* skip index: launches of k_scan_skip and the tiles they actually read (the rest was skipped by signature) */
     uint64_t scan_skip_launches;
     uint64_t scan_skip_tiles_read;
+    /* candidate argmax: list rebuilds (one per check interval) and merges that fell back to the full table scan */
+    uint64_t cand_rebuilds;
+    uint64_t cand_rescans;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

@@ -118,7 +118,7 @@ struct yabpe_ctx {
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
     Best *partials = nullptr;
-    uint32_t n_partials = 0;
+    uint32_t n_partials = 0, n_partials_cap = 0;
     // records of the last train call
     uint32_t rec_cap = 0, rec_n = 0;
     uint32_t *rec_left = nullptr, *rec_right = nullptr, *rec_merged = nullptr;
@@ -151,6 +151,11 @@ struct yabpe_ctx {
     bool sig_valid = false;
     uint32_t sig_built_at = 0;
     bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
+    // candidate argmax
+    CandState *cand_state = nullptr;
+    uint32_t *cand = nullptr;
+    bool use_cand = false;
+    uint64_t cand_rebuilds = 0, cand_rescans = 0;
     // multi-GPU
     int rank = 0, n_ranks = 1;
     bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
@@ -260,8 +265,11 @@ int state_push(yabpe_ctx *c) {
 void table_free(PairTable &t) {
     dfree(t.keys);
     dfree(t.cnt);
+    dfree(t.touched);
+    dfree(t.incand);
     t.keys = nullptr;
     t.cnt = nullptr;
+    t.touched = t.incand = nullptr;
 }
 
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
@@ -270,8 +278,48 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.cap = (uint32_t)cap;
     t.max_probe = (uint32_t)std::min<uint64_t>(cap, 2048);
     t.entries = entries_ctr;
+    t.touched = t.incand = nullptr;  // attached to the main table only, once it is built (cand_attach)
     HIPCHK(c, hipMemsetAsync(t.keys, 0xFF, cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(unsigned long long), c->stream));
+    return 0;
+}
+
+// bitmaps of the candidate argmax for the main table (cleared; the candidate list is rebuilt by the caller's next check)
+int cand_attach(yabpe_ctx *c) {
+    c->use_cand = false;
+    if (!optv(c, "cand_argmax", 1)) return 0;
+    PairTable &t = c->table;
+    const uint64_t words = ((uint64_t)t.cap + 31) / 32 + 1;
+    if (!t.touched) {
+        TRY(dmalloc(c, &t.touched, words));
+        TRY(dmalloc(c, &t.incand, words));
+    }
+    HIPCHK(c, hipMemsetAsync(t.touched, 0, words * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
+    if (!c->cand_state) {
+        TRY(dmalloc(c, &c->cand_state, 1));
+        TRY(dmalloc(c, &c->cand, CAND_CAP));
+    }
+    return 0;
+}
+
+// cand[] = every slot with count >= 0.8 x best_count; enables the candidate argmax for the next batch
+int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
+    c->use_cand = false;
+    if (!optv(c, "cand_argmax", 1) || !c->table.touched || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
+    const uint64_t words = ((uint64_t)c->table.cap + 31) / 32 + 1;
+    HIPCHK(c, hipMemsetAsync(c->table.touched, 0, words * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
+    CandState h{best_count - best_count / 5, 0u, 0u};
+    HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    CandParams P{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand};
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
+    hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h, c->cand_state, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cand_rebuilds++;
+    c->use_cand = !h.overflow && h.n < CAND_CAP / 2;
     return 0;
 }
 
@@ -461,6 +509,7 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
                 continue;
             }
             c->stats.table_rebuilds++;
+            TRY(cand_attach(c));
             return 0;
         }
         cap *= 4;
@@ -485,6 +534,7 @@ int table_grow(yabpe_ctx *c, uint64_t new_cap) {
             c->table = nt;
             c->table_cap = new_cap;
             c->stats.table_rebuilds++;
+            TRY(cand_attach(c));
             return 0;
         }
         table_free(nt);
@@ -673,6 +723,8 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->work_cnt);
     dfree(c->work_dense);
     dfree(c->blk_read);
+    dfree(c->cand_state);
+    dfree(c->cand);
     table_free(c->delta);
     dfree(c->xsend);
     dfree(c->xrecv);
@@ -923,6 +975,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.scan_algo_bytes_sampled = 0;
     c->stats.scan_actual_bytes_sampled = 0;
     c->scan_skip_launches = 0;
+    c->cand_rebuilds = c->cand_rescans = 0;
     if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
@@ -949,11 +1002,19 @@ static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
 }
 
 static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev) {
-    ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
-    hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
-    SelectParams S{c->partials, c->n_partials, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
+    uint32_t n_part = c->n_partials;
+    if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
+        n_part = std::min<uint32_t>(c->n_partials_cap, 64);
+        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand};
+        hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
+    } else {
+        ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
+        hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
+    }
+    SelectParams S{c->partials, n_part, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
                    c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
-                   c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u)};
+                   c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u),
+                   c->use_cand ? c->cand_state : nullptr};
     hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
     const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
@@ -1104,13 +1165,16 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     uint32_t tokens_start = h->n_tokens;
     uint32_t i = 0;
     bool finished = false;
+    bool skip_cand_once = false;
+    c->use_cand = false;
     while (!finished) {
         // (re)size the argmax grid to the table
         uint32_t want_partials = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
         if (want_partials != c->n_partials) {
             dfree(c->partials);
             c->partials = nullptr;
-            TRY(dmalloc(c, &c->partials, want_partials));
+            c->n_partials_cap = std::max<uint32_t>(want_partials, 64);
+            TRY(dmalloc(c, &c->partials, c->n_partials_cap));
             c->n_partials = want_partials;
         }
         const uint32_t apply_grid = count_grid(c);
@@ -1125,6 +1189,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
             const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
             c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < 256.0);
+        }
+        if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
+            c->use_cand = false;
+            skip_cand_once = false;
+        } else if (h->iter > rec_base) {
+            TRY(cand_rebuild(c, h->best_count));
         }
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
@@ -1158,6 +1228,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
             TRY(comm_max(c, sig, &mx));
             if (mx != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, mx);
+        }
+        if (h->halt == HALT_RESCAN) {  // the candidate set could not prove the maximum: redo that merge with the full scan
+            h->halt = 0; h->halt_req = 0;
+            TRY(state_push(c));
+            c->cand_rescans++;
+            skip_cand_once = true;
+            i = h->iter - rec_base;
+            continue;
         }
         if (h->halt) {
             if (h->halt == HALT_TABLE_FULL || h->halt == HALT_DELTA_FULL) {
@@ -1294,6 +1372,8 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.live_slots = c->st_host->live_slots;
     c->stats.table_capacity = c->table_cap;
     c->stats.table_entries = c->st_host->table_entries;
+    c->stats.cand_rebuilds = c->cand_rebuilds;
+    c->stats.cand_rescans = c->cand_rescans;
     c->stats.scan_skip_launches = c->scan_skip_launches;
     c->stats.scan_skip_tiles_read = 0;
     if (c->blk_read) {

@@ -38,7 +38,7 @@ constexpr int SIG_WORDS = TOK_WORDS + PAIR_WORDS;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time
 constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
-enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4 };
+enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
 
 struct DevState {
     uint32_t iter;       // merges recorded so far
@@ -69,6 +69,8 @@ struct PairTable {
     uint32_t cap;       // any size >= 2 (not only powers of two: the argmax scan reads every slot, so the table is kept small)
     uint32_t max_probe;
     unsigned long long *entries; // where successful inserts are counted
+    uint32_t *touched;           // optional bitmap: slots that received a positive update since k_argmax_cand last looked
+    uint32_t *incand;            // optional bitmap: slots already in the candidate list
 };
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
 __device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
@@ -82,6 +84,12 @@ struct Best {
     uint32_t key;  // left << 16 | right
     uint32_t slot; // table slot of the entry
     uint32_t pad;
+};
+
+// candidate argmax state (see k_argmax_cand)
+struct CandState {
+    unsigned long long T;
+    uint32_t n, overflow;
 };
 
 // multi-GPU delta exchange records (see k_delta_extract)
@@ -147,6 +155,10 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
         }
         if (k == key) {
             atomicAdd(&t.cnt[s], (unsigned long long)d);
+            if (d > 0 && t.touched) { // a count went up: the candidate argmax must look at this slot again
+                const uint32_t bit = 1u << (s & 31);
+                if (!(t.touched[s >> 5] & bit)) atomicOr(&t.touched[s >> 5], bit);
+            }
             return;
         }
         s = pt_next(t, s);
@@ -1659,6 +1671,7 @@ struct SelectParams {
     DeltaHdr *delta_hdr;                // multi-GPU: this rank's send header (count reset here), else NULL
     unsigned long long *blk_stats;      // per-workgroup counters of the last k_apply
     uint32_t n_blk;
+    const CandState *cs;                // != NULL: the partials come from k_argmax_cand
 };
 
 // Adds the per-workgroup counters of the last apply pass to DevState and clears them (one workgroup).
@@ -1728,9 +1741,14 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         best = s_b[0];
         // close the log entry of the previous iteration
         const uint32_t it = st->iter;
-        if (it > P.rec_base) P.rec_sites[it - 1 - P.rec_base] = st->sites;
+        if (it > P.rec_base && st->sites) P.rec_sites[it - 1 - P.rec_base] = st->sites; // (0: already closed, this is a re-run)
         st->tokens_now -= st->sites;
         st->sites = 0;
+        if (P.cs && it < st->num_merges && (best.cnt < P.cs->T || P.cs->overflow)) {
+            // the candidate set no longer proves that this is the maximum: the host redoes this merge with a full scan
+            st->halt = HALT_RESCAN;
+            s_flag = 1;
+        } else
         // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
         if (it >= st->num_merges || best.cnt == 0 || best.cnt < st->min_freq) {
             st->done = 1;
@@ -1923,6 +1941,82 @@ __global__ __launch_bounds__(BLOCK) void k_sum_u32(const uint32_t *p, unsigned l
     for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) s += p[i];
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// ================================================================ candidate argmax (exact, without reading the whole table)
+// Invariant kept between two host rebuilds: every slot whose count is >= T is in cand[] or has its `touched` bit set.
+//   - k_cand_rebuild (host, every check interval): cand = all slots with count >= T, T = 0.8 x the last best count;
+//   - counts only go UP through gt_add, which sets the touched bit; k_argmax_cand evaluates every touched slot,
+//     appends the ones that reached T and clears the bits.
+// So max over (cand U touched) is the true maximum -- with all its ties -- whenever that maximum is >= T.  If it is
+// not (the best count decayed below T, or cand[] overflowed), k_select stops with HALT_RESCAN and the host finishes
+// the batch with the full scan.  The best count is non-increasing over merges, so T is refreshed about every 64.
+constexpr uint32_t CAND_CAP = 1u << 16;
+struct CandParams {
+    PairTable table;
+    const uint32_t *rank;
+    Best *partials;
+    DevState *st;
+    CandState *cs;
+    uint32_t *cand;
+};
+
+__device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best &best) {
+    const long long cn = (long long)P.table.cnt[s];
+    if (cn <= 0 || (unsigned long long)cn < best.cnt) return;
+    const uint32_t k = P.table.keys[s];
+    if (k == EMPTY) return;
+    Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
+    if (best_gt(e, best)) best = e;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
+    __shared__ Best s_b[WPB];
+    if (P.st->done | P.st->halt) return;
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
+    const unsigned long long T = P.cs->T;
+    const uint32_t n0 = min(P.cs->n, CAND_CAP);
+    const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
+    for (uint32_t i = tid; i < n0; i += nth) cand_eval(P, P.cand[i], best);
+    const uint32_t words = (P.table.cap + 31) >> 5;
+    for (uint32_t w = tid; w < words; w += nth) {
+        uint32_t bits = P.table.touched[w];
+        if (!bits) continue;
+        P.table.touched[w] = 0u;
+        while (bits) {
+            const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
+            bits &= bits - 1;
+            cand_eval(P, s, best);
+            if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
+                const uint32_t bit = 1u << (s & 31);
+                if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
+                    const uint32_t idx = atomicAdd(&P.cs->n, 1u);
+                    if (idx < CAND_CAP) P.cand[idx] = s; else P.cs->overflow = 1u;
+                }
+            }
+        }
+    }
+    best = best_wave_reduce(best);
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if (lane == 0) s_b[wib] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < WPB; ++i)
+            if (best_gt(s_b[i], best)) best = s_b[i];
+        P.partials[blockIdx.x] = best;
+    }
+}
+
+// cand = every slot with count >= cs->T (the bitmaps were cleared by the host)
+__global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
+    const unsigned long long T = P.cs->T;
+    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < P.table.cap; s += gridDim.x * BLOCK) {
+        const long long cn = (long long)P.table.cnt[s];
+        if (cn <= 0 || (unsigned long long)cn < T) continue;
+        atomicOr(&P.table.incand[s >> 5], 1u << (s & 31));
+        const uint32_t idx = atomicAdd(&P.cs->n, 1u);
+        if (idx < CAND_CAP) P.cand[idx] = s; else P.cs->overflow = 1u;
+    }
 }
 
 // ================================================================ table growth: re-insert live entries (count != 0)

@@ -28,7 +28,7 @@ class Stats(ctypes.Structure):
         ("load_ms", c_double), ("train_ms", c_double), ("apply_ms_sampled", c_double)] + [(n, c_uint64) for n in (
             "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")] + [
         ("scan_ms_sampled", c_double)] + [(n, c_uint64) for n in (
-            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read")]
+            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans")]
 
 
 _lib = None
