@@ -159,11 +159,22 @@ def test_many_tiles_retile_and_table_growth():
     assert s2["retiles"] >= 1
     # the plain streaming scan (skip index off) and the always-split / never-split forms give the same result
     for opts in ({"skip_index": 0}, {"split": 1}, {"split": 0}, {"sig_rebuild_every": 3, "check_interval": 2}, {"fuse_skip": 1}, {"inline_single": 0}, {"rank_rides": 0}, {"dense_worklist": 1}, {"dense_worklist": 0}, {"cand_argmax": 0}, {"cand_min_count": 1, "check_interval": 3},
+                 {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
                  {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16}):
         v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
         assert (v3, m3) == (exp_vocab, exp_merges), opts
     assert s1["scan_skip_launches"] > 0 and s1["scan_skip_tiles_read"] < s1["scan_skip_launches"] * s1["n_tiles"]
     assert s1["tokens_initial"] - s1["tokens_now"] == s2["tokens_initial"] - s2["tokens_now"]
+
+
+def test_weighted_layout_split_forms():
+    """Pooled words + counts through every form of the split apply (lists, dense list, rewrite inside the scan)."""
+    words = helpers.corpus_en_words()
+    uw, fq = helpers.pooled(words)
+    exp = oracle.merge_loop(words, 257 + 1200, 1, SP)
+    for opts in ({"split": 1}, {"split": 1, "dense_worklist": 1}, {"split": 1, "dense_worklist": 1, "full_skip": 0},
+                 {"split": 1, "dense_worklist": 0}, {"split": 1, "skip_index": 0}):
+        assert gpu_train(uw, fq, 257 + 1200, 1, SP, options={"verify": 1, **opts}) == exp, opts
 
 
 def test_continue_training_equals_one_shot():

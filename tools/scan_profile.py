@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Dev tool: timeline of one k_scan_skip launch (needs libyabpe_scanprof.so: make -C yet-another-bpe_amd/csrc libyabpe_scanprof.so).
+Every workgroup stamps the 100 MHz wall clock at: 0 start, 1 signatures tested, 2 candidates matched, 3 single-site
+rewrites done, 4 loop left, 7 end (after the aggregator flush).  Prints the spread of each phase over the workgroups."""
+import ctypes, os, sys
+from pathlib import Path
+REPO = Path(__file__).resolve().parent.parent
+os.environ["YABPE_LIB"] = str(REPO / "yet-another-bpe_amd/csrc/libyabpe_scanprof.so")
+sys.path.insert(0, str(REPO / "yet-another-bpe_amd"))
+import numpy as np
+from yet_another_bpe import _native, synth
+merges = [int(x) for x in (sys.argv[1:] or ["3000", "20000"])]
+spec = synth.SynthSpec.config3(1024 << 20)
+base = [bytes([b]) for b in range(256)] + [b"<|endoftext|>"]
+NB = 4096
+with _native.Context() as g:
+    pb, po, nw, nb = g.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
+    with _native.Context() as ctx:
+        ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw)
+        done = 0
+        for m in merges:
+            ctx.train(m - done, 1); done = m
+            st = ctx.stats()
+            out = np.zeros(NB * 8, dtype=np.uint64)
+            _native.lib().yabpe_debug_scan_profile(ctypes.c_void_p(out.ctypes.data), ctypes.c_uint32(NB))
+            p = out.reshape(NB, 8).astype(np.int64)
+            n256 = (st["n_tiles"] + 255) // 256; target = 1024
+            kt = min(4, max(1, -(-n256 // target)))
+            n_scan = min(-(-st["n_tiles"] // (256 * kt)), target)
+            recent = p[:, 7].max() - 30000  # stamps older than 300 us belong to earlier launches
+            scan = p[:n_scan]; rank = p[n_scan:]; rank = rank[rank[:, 0] > recent]
+            scan = scan[scan[:, 0] > recent]
+            t0 = min(scan[:, 0].min(), rank[:, 0].min() if len(rank) else scan[:, 0].min())
+            us = lambda x: x / 100.0
+            print(f"--- after {m} merges: n_tiles {st['n_tiles']} scan blocks {n_scan} rank blocks {len(rank)}")
+            print(f"span scan blocks: first start 0, last start {us(scan[:,0].max()-t0):.2f}, last end {us(scan[:,7].max()-t0):.2f} us")
+            if len(rank):
+                print(f"rank blocks: start {us(rank[:,0].min()-t0):.2f}..{us(rank[:,0].max()-t0):.2f}, end max {us(rank[:,7].max()-t0):.2f}, dur mean {us((rank[:,7]-rank[:,0]).mean()):.2f} max {us((rank[:,7]-rank[:,0]).max()):.2f}")
+            names = ["start->sig tested", "sig->candidates matched", "cand->rewrites done", "rewrites->loop left", "flush (epilogue)"]
+            idx = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 7)]
+            for nm, (a, b) in zip(names, idx):
+                d = us(scan[:, b] - scan[:, a])
+                print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            d = us(scan[:, 7] - scan[:, 0])
+            print(f"  {'whole block':28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            for k in (1, 2, 3, 4, 7):
+                print(f"  stamp {k}: min {us(scan[:,k].min()-t0):7.2f} max {us(scan[:,k].max()-t0):7.2f}")

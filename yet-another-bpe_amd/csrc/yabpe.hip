@@ -150,6 +150,8 @@ struct yabpe_ctx {
     uint64_t scan_skip_launches = 0;
     bool sig_valid = false;
     uint32_t sig_built_at = 0;
+    uint64_t sig_tokens_at_build = 0;  // T when the signatures were last built (stale bits grow with the sites merged since)
+    uint64_t sig_builds = 0;
     bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
     // candidate argmax
     CandState *cand_state = nullptr;
@@ -598,11 +600,14 @@ int build_signatures(yabpe_ctx *c) {
     if (!c->sig || c->sig_stride < c->n_tiles) {
         dfree(c->sig);
         c->sig = nullptr;
-        c->sig_stride = c->n_tiles;
+        c->sig_stride = (uint32_t)((c->n_tiles + 31u) & ~31u);  // rows start 128-B aligned
         TRY(dmalloc(c, &c->sig, (uint64_t)SIG_WORDS * c->sig_stride));
     }
     SigParams P{c->tiles, c->tile_len, c->n_tiles, c->sig, c->sig_stride};
-    hipLaunchKernelGGL(k_build_sig, dim3(count_grid(c)), dim3(BLOCK), 0, c->stream, P);
+    const uint32_t n_groups = (uint32_t)((c->n_tiles + SIG_TILES - 1) / SIG_TILES);
+    hipLaunchKernelGGL(k_build_sig, dim3(std::min<uint32_t>(n_groups, 256 * 3)), dim3(BLOCK), 0, c->stream, P);
+    c->sig_tokens_at_build = c->st_host->tokens_now;
+    c->sig_builds++;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1040,6 +1045,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
             // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
             const uint32_t want = (c->n_tiles + WPB - 1) / WPB;
             uint32_t scan_grid = 0, seg = 0;
+            bool skip_slow = false;
             const bool use_sig = c->sig && c->sig_valid;
             if (use_sig && optv(c, "fuse_skip", 0)) {
                 // signatures + rewrite in one launch, dynamically scheduled
@@ -1056,18 +1062,37 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
             } else {
             if (use_sig) {
-                const uint32_t n_chunks = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-                scan_grid = std::max(1u, std::min<uint32_t>(n_chunks, MAX_LISTS));
-                seg = SCAN_CHUNK * ((n_chunks + scan_grid - 1) / scan_grid);
+                // a grid that is resident all at once (no second round of workgroups behind the first): each thread tests
+                // kt tiles' signatures, a workgroup owns SCAN_CHUNK * kt consecutive tiles at a time
+                const uint32_t n256 = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+                // sparse merges: the scan also rewrites the few tiles with several sites itself -- no k_slow launch
+                const bool full = c->dense_mode && optv(c, "full_skip", 1);
+                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * 3))
+                                             : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
+                const uint32_t kt = std::min<uint32_t>(SCAN_KT_MAX, std::max<uint32_t>(1, (n256 + target - 1) / target));
+                const uint32_t chunk = SCAN_CHUNK * kt;
+                const uint32_t n_chunks = (c->n_tiles + chunk - 1) / chunk;
+                scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n_chunks, target), MAX_LISTS));
+                seg = chunk * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
-                                  scan_grid, c->dense_mode ? c->work_dense : nullptr, DENSE_CAP, R};
+                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, R};
                 c->blk_used = std::max(c->blk_used, scan_grid);
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
-                if (!c->weighted && optv(c, "inline_single", 1))
-                    hipLaunchKernelGGL(k_scan_skip<true>, dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
-                else
-                    hipLaunchKernelGGL(k_scan_skip<false>, dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                const bool inl = !c->weighted && optv(c, "inline_single", 1);
+                if (full) {
+                    if (c->weighted)
+                        hipLaunchKernelGGL((k_scan_skip<false, true, true>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                    else if (inl)
+                        hipLaunchKernelGGL((k_scan_skip<true, true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                    else
+                        hipLaunchKernelGGL((k_scan_skip<false, true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                    skip_slow = true;
+                } else if (inl) {
+                    hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                } else {
+                    hipLaunchKernelGGL((k_scan_skip<false, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                }
                 c->scan_skip_launches++;
             } else {
                 scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 4)), MAX_LISTS));
@@ -1077,6 +1102,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
             }
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
+            if (!skip_slow) {
             const bool dense = use_sig && c->dense_mode;
             const uint32_t slow_grid = dense ? std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks_dense", 128)))
                                              : std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
@@ -1086,6 +1112,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 hipLaunchKernelGGL(k_slow<true>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
             else
                 hipLaunchKernelGGL(k_slow<false>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
+            }
             }
         }
     } else if (ev) {
@@ -1198,8 +1225,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         }
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
+            // (rewrites only ever ADD bits: every merged site leaves up to two new pairs and three stale ones behind)
             const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 4096));
-            if (!c->sig_valid || i - c->sig_built_at >= every) {
+            const uint64_t merged_since = c->sig_tokens_at_build > h->tokens_now ? c->sig_tokens_at_build - h->tokens_now : 0;
+            const bool stale = merged_since * 100 > c->sig_tokens_at_build * (uint64_t)optv(c, "sig_rebuild_pct", 12);
+            if (!c->sig_valid || i - c->sig_built_at >= every || stale) {
                 TRY(build_signatures(c));
                 c->sig_valid = true;
                 c->sig_built_at = i;
@@ -1455,6 +1485,11 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
     return YABPE_OK;
 }
 
+#ifdef YB_PROFILE_SCAN
+int yabpe_debug_scan_profile(unsigned long long *out, uint32_t n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_scan_prof), (size_t)std::min<uint32_t>(n_blocks, yb::MAX_LISTS_PROF) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef YB_PROFILE_SLOW
 int yabpe_debug_slow_profile(unsigned long long out[8]) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_slow_prof), 64) == hipSuccess ? 0 : -1;

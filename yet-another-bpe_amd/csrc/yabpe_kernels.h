@@ -32,10 +32,14 @@ constexpr int AGG_N = 1024;          // LDS delta-aggregator entries per workgro
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PADPAD = (YB_PAD << 16) | YB_PAD;
 constexpr int LONG_CH = 4096;        // long-word path: tokens per LDS chunk
-constexpr int TOK_WORDS = 64;        // tile signature, part 1: 2,048-bit set of the token ids present in the tile
-constexpr int PAIR_WORDS = 128;      // part 2: 4,096-bit set of the adjacent pairs present in the tile
-constexpr int SIG_WORDS = TOK_WORDS + PAIR_WORDS;
-constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time
+constexpr int SIG_K = 3;             // tile signature: a Bloom filter of the adjacent pairs present in the tile, SIG_K hash
+constexpr int SIG_PART_LOG2 = 13;    // functions, each with its own partition of 8,192 bits (a tile holds <= 1023 pairs)
+constexpr int SIG_PART_WORDS = 1 << (SIG_PART_LOG2 - 5);
+constexpr int SIG_WORDS = SIG_K * SIG_PART_WORDS;
+constexpr int SIG_TILES = 16;        // k_build_sig: tiles whose signatures one workgroup transposes together (64-B rows)
+constexpr int MAX_LISTS_PROF = 4096;
+constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time (x kt)
+constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
 constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
@@ -112,23 +116,57 @@ __device__ __forceinline__ uint32_t hash32(uint32_t k) {
 }
 
 // Tile signatures (skip index).  sig[w * stride + tile], w < SIG_WORDS: transposed, so that the threads of a workgroup
-// that test 256 consecutive tiles read consecutive words.  Rows [0, TOK_WORDS): token bits; rows [TOK_WORDS, SIG_WORDS):
-// pair bits.  A signature is a SUPERSET of what the tile holds: bits are added when a rewrite creates a token / pair
-// and only a rebuild (k_build_sig) clears stale ones.
-__device__ __forceinline__ uint32_t sig_bit(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - 11); } // 0 .. 2047
-__device__ __forceinline__ uint32_t pair_bit(uint32_t key) { // key = left << 16 | right ; 0 .. 4095
-    uint32_t k = key * 0x9E3779B1u;
-    k ^= k >> 15;
-    k *= 0x85EBCA77u;
-    return k >> (32 - 12);
+// that test 256 consecutive tiles read consecutive words.  Partition k (rows [k * SIG_PART_WORDS, (k+1) * SIG_PART_WORDS))
+// holds bit h_k(pair) for every adjacent pair of the tile.  A signature is a SUPERSET of what the tile holds: bits are
+// added when a rewrite creates a pair and only a rebuild (k_build_sig) clears stale ones.  With ~1,000 pairs per tile the
+// partitions are ~11 % full, so a tile without the pair passes all three tests with probability ~0.1 %.
+struct SigHash {
+    uint32_t row[SIG_K]; // word row inside the signature
+    uint32_t bit[SIG_K]; // bit inside that word
+};
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
 }
-__device__ __forceinline__ void sig_set_tok(uint32_t *sig, uint32_t stride, uint32_t tile, uint32_t t) {
-    const uint32_t h = sig_bit(t);
-    atomicOr(&sig[(size_t)(h >> 5) * stride + tile], 1u << (h & 31));
+__device__ __forceinline__ SigHash sig_hash(uint32_t key) { // key = left << 16 | right
+    const uint32_t x = fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
+    const uint32_t y = fmix32(key ^ 0x5BD1E995u);
+    const uint32_t h0 = x >> (32 - SIG_PART_LOG2), h1 = x & ((1u << SIG_PART_LOG2) - 1u), h2 = y >> (32 - SIG_PART_LOG2);
+    SigHash H;
+    H.row[0] = h0 >> 5;
+    H.row[1] = SIG_PART_WORDS + (h1 >> 5);
+    H.row[2] = 2 * SIG_PART_WORDS + (h2 >> 5);
+    H.bit[0] = h0 & 31;
+    H.bit[1] = h1 & 31;
+    H.bit[2] = h2 & 31;
+    return H;
 }
 __device__ __forceinline__ void sig_set_pair(uint32_t *sig, uint32_t stride, uint32_t tile, uint32_t key) {
-    const uint32_t h = pair_bit(key);
-    atomicOr(&sig[(size_t)(TOK_WORDS + (h >> 5)) * stride + tile], 1u << (h & 31));
+    const SigHash H = sig_hash(key);
+#pragma unroll
+    for (int k = 0; k < SIG_K; ++k) atomicOr(&sig[(size_t)H.row[k] * stride + tile], 1u << H.bit[k]);
+}
+// The three words a scan tests for one tile, as row pointers (the pair is fixed for the whole launch).
+struct SigProbe {
+    const uint32_t *p[SIG_K];
+    uint32_t bit[SIG_K];
+    __device__ __forceinline__ bool maybe(uint32_t tile) const {
+        return ((p[0][tile] >> bit[0]) & (p[1][tile] >> bit[1]) & (p[2][tile] >> bit[2]) & 1u) != 0;
+    }
+};
+__device__ __forceinline__ SigProbe sig_probe(const uint32_t *sig, uint32_t stride, uint32_t key) {
+    const SigHash H = sig_hash(key);
+    SigProbe Q;
+#pragma unroll
+    for (int k = 0; k < SIG_K; ++k) {
+        Q.p[k] = sig + (size_t)H.row[k] * stride;
+        Q.bit[k] = H.bit[k];
+    }
+    return Q;
 }
 
 // Within one wave LDS operations complete in order; this keeps the compiler from moving a lane's LDS reads
@@ -580,13 +618,12 @@ __device__ __forceinline__ uint32_t tile_elem_uniform(const TileRegs &r, int q) 
     if (q < 0 || q >= CAP) return YB_PAD;
     const bool segB = q >= 512;
     const int l = (q >> 3) & 63, e = q & 7;
-    uint32_t d;
-    switch (e >> 1) {
-        case 0: d = segB ? r.vb.x : r.va.x; break;
-        case 1: d = segB ? r.vb.y : r.va.y; break;
-        case 2: d = segB ? r.vb.z : r.va.z; break;
-        default: d = segB ? r.vb.w : r.va.w; break;
-    }
+    // (values first, selects second: a conditional between the two MEMBERS makes the compiler keep r in scratch)
+    const uint32_t ax = r.va.x, ay = r.va.y, az = r.va.z, aw = r.va.w;
+    const uint32_t bx = r.vb.x, by = r.vb.y, bz = r.vb.z, bw = r.vb.w;
+    const uint32_t x = segB ? bx : ax, y = segB ? by : ay, z = segB ? bz : az, w4 = segB ? bw : aw;
+    const uint32_t d01 = (e & 2) ? y : x, d23 = (e & 2) ? w4 : z;
+    const uint32_t d = (e & 4) ? d23 : d01;
     const uint32_t w = __builtin_amdgcn_readlane(d, l);
     return (e & 1) ? (w >> 16) : (w & 0xffffu);
 }
@@ -638,7 +675,6 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         upd(yb_pairkey(c, R), +1, 3);
     }
     if (P.sig && lane == 0 && !dead) {
-        sig_set_tok(P.sig, P.sig_stride, tile, c);
         if (left) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(L, c));
         if (right) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(c, R));
     }
@@ -769,7 +805,6 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
     YB_STAMP(1);
     // ---- deltas + drop marks: each lane walks its own sites (usually none or one)
     uint32_t mm = mA | (mB << 8);
-    if (P.sig && lane == 0) sig_set_tok(P.sig, P.sig_stride, tile, c); // the tile now holds c
     {
         uint32_t tot = __popc(mm);
 #pragma unroll
@@ -1095,16 +1130,20 @@ struct SigParams {
     uint32_t sig_stride;
 };
 __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
-    __shared__ uint32_t s_sig[WPB][SIG_WORDS];
+    constexpr int ROW = SIG_WORDS + 4; // +4: the transposed read below walks the tiles with a stride of 4 banks
+    __shared__ uint32_t s_sig[SIG_TILES][ROW];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *sg = s_sig[wib];
-    const uint32_t stride = gridDim.x * WPB;
-    for (uint32_t tile = blockIdx.x * WPB + wib; tile < P.n_tiles; tile += stride) {
-        const uint32_t len = P.tile_len[tile];
-        for (int w = lane; w < SIG_WORDS; w += 64) sg[w] = 0u;
-        wave_sync();
-        if (len) {
+    const uint32_t n_groups = (P.n_tiles + SIG_TILES - 1) / SIG_TILES;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t base = grp * SIG_TILES;
+        for (int w = threadIdx.x; w < SIG_TILES * ROW; w += BLOCK) (&s_sig[0][0])[w] = 0u;
+        __syncthreads();
+        for (int k = wib; k < SIG_TILES; k += WPB) {
+            const uint32_t tile = base + k;
+            const uint32_t len = tile < P.n_tiles ? P.tile_len[tile] : 0u;
+            if (!len) continue;
+            uint32_t *sg = s_sig[k];
             const TileRegs r = load_tile(P.tiles, tile, len, lane);
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
@@ -1118,26 +1157,36 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t x = elem16(v, j);
                     const uint32_t y = j < 7 ? elem16(v, j + 1) : nx;
-                    if (p0 + j < len && x < YB_PAD) {
-                        const uint32_t h = sig_bit(x);
-                        atomicOr(&sg[h >> 5], 1u << (h & 31));
-                        if (y < YB_PAD) {
-                            const uint32_t hp = pair_bit(yb_pairkey(x, y));
-                            atomicOr(&sg[TOK_WORDS + (hp >> 5)], 1u << (hp & 31));
-                        }
+                    if (p0 + j < len && x < YB_PAD && y < YB_PAD) {
+                        const SigHash H = sig_hash(yb_pairkey(x, y));
+#pragma unroll
+                        for (int q = 0; q < SIG_K; ++q) atomicOr(&sg[H.row[q]], 1u << H.bit[q]);
                     }
                 }
             }
         }
-        wave_sync();
-        for (int w = lane; w < SIG_WORDS; w += 64) P.sig[(size_t)w * P.sig_stride + tile] = sg[w];
-        wave_sync();
+        __syncthreads();
+        // transposed store: 16 consecutive tiles of one row are 64 contiguous bytes
+        for (int idx = threadIdx.x; idx < SIG_WORDS * SIG_TILES; idx += BLOCK) {
+            const int row = idx / SIG_TILES, col = idx % SIG_TILES;
+            if (base + col < P.n_tiles) P.sig[(size_t)row * P.sig_stride + base + col] = s_sig[col][row];
+        }
+        __syncthreads();
     }
 }
 
 // Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
 // tile's signature (16 B per tile: length + the words holding bit(a), bit(b) and bit(a,b)); the tiles that may contain
 // the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
+#ifdef YB_PROFILE_SCAN
+__device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];
+#define YB_SCAN_STAMP(i)                                                                       \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < MAX_LISTS_PROF) g_scan_prof[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define YB_SCAN_STAMP(i) do { } while (0)
+#endif
 struct ScanSkipParams {
     ScanParams S;
     ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
@@ -1145,41 +1194,50 @@ struct ScanSkipParams {
     uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
     uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
     uint32_t dense_cap;
+    uint32_t kt;                  // signature tests per thread: a workgroup takes SCAN_CHUNK * kt consecutive tiles at a time
     RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
 };
 
 // INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
 // (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
-template <bool INLINE>
+// FULL (sparse merges): the rest is rewritten here too (slow_tile) -- the few tiles involved do not need k_slow's
+// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.
+template <bool INLINE, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    constexpr bool REWRITES = INLINE || FULL;
+    static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
     __shared__ uint32_t s_n, s_hits, s_nrew;
-    __shared__ uint2 s_list[SCAN_CHUNK];
-    __shared__ uint2 s_rew[INLINE ? SCAN_CHUNK : 1];
-    __shared__ uint32_t s_keys[INLINE ? AGG_N : 1];
-    __shared__ int s_vals[INLINE ? AGG_N : 1];
+    __shared__ uint2 s_list[SCAN_CHUNK * SCAN_KT_MAX];
+    __shared__ uint2 s_rew[REWRITES ? SCAN_CHUNK * SCAN_KT_MAX : 1];
+    __shared__ uint32_t s_keys[REWRITES ? AGG_N : 1];
+    __shared__ AggV s_vals[REWRITES ? AGG_N : 1];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? WPB : 1];
     __shared__ unsigned long long s_cnt[2];
     const ScanParams &P = Q.S;
     DevState *st = P.st;
+    YB_SCAN_STAMP(0);
     if (blockIdx.x >= Q.scan_blocks) {
         rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
+        YB_SCAN_STAMP(7);
         return;
     }
     if (st->done | st->halt) return;
     const uint32_t n_blocks = Q.scan_blocks;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<int> C{Q.A, Agg<int>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                   KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     const uint32_t a = C.a, b = C.b;
     const uint32_t mk = yb_memkey(a, b);
     C.mk = mk;
     C.self = yb_pairkey(a, b);
-    const bool do_inline = INLINE && a != b;
-    const uint32_t ha = sig_bit(a), hb = sig_bit(b), hp = pair_bit(yb_pairkey(a, b));
-    const uint32_t *sa = Q.A.sig + (size_t)(ha >> 5) * Q.A.sig_stride;
-    const uint32_t *sb = Q.A.sig + (size_t)(hb >> 5) * Q.A.sig_stride;
-    const uint32_t *sp = Q.A.sig + (size_t)(TOK_WORDS + (hp >> 5)) * Q.A.sig_stride;
-    if (INLINE) agg_init(C.agg);
+    const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
+    const bool single_ok = INLINE && a != b;
+    const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
+    if (REWRITES) agg_init(C.agg);
+    WaveLds &W = s_w[FULL ? wib : 0];
+    if (FULL) wave_lds_init(W, lane);
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         s_n = 0;
@@ -1189,20 +1247,34 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     __syncthreads();
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
-    const uint32_t n_chunks = (P.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const uint32_t kt = Q.kt;
+    const uint32_t chunk = SCAN_CHUNK * kt;
+    const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
     for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
-        const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
-        uint32_t len = 0;
-        bool maybe = false;
-        if (t < P.n_tiles) {
-            len = P.tile_len[t];
-            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & (sp[t] >> (hp & 31)) & 1u);
+        // all of this thread's signature words are requested before the first one is looked at
+        uint32_t len[SCAN_KT_MAX];
+        bool maybe[SCAN_KT_MAX];
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
+            const uint32_t t = ch * chunk + j * SCAN_CHUNK + threadIdx.x;
+            len[j] = 0;
+            maybe[j] = false;
+            if (j < kt && t < P.n_tiles) {
+                len[j] = P.tile_len[t];
+                maybe[j] = probe.maybe(t);
+            }
         }
-        const unsigned long long m = __ballot(maybe);
-        uint32_t base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (maybe) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(t, len);
+        YB_SCAN_STAMP(1);
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
+            if (j >= kt) break; // uniform
+            const bool mb = maybe[j] && len[j] != 0;
+            const unsigned long long m = __ballot(mb);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * SCAN_CHUNK + threadIdx.x, len[j]);
+        }
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
@@ -1240,6 +1312,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
             }
         }
         __syncthreads();
+        YB_SCAN_STAMP(2);
         if (do_inline) {
             const uint32_t nr = s_nrew;
             uint32_t k = wib;
@@ -1264,21 +1337,30 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
                 const unsigned long long holders = __ballot(mine != 0);
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
-                if (__popcll(holders) == 1 && __popc(mm_s) == 1) {
-                    single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                bool handled = false;
+                if constexpr (INLINE) {
+                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
+                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        handled = true;
+                    }
+                }
+                if (handled) {
+                } else if constexpr (FULL) {
+                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
                 } else if (lane == 0) {
                     my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
                 }
             }
             __syncthreads();
         }
+        YB_SCAN_STAMP(3);
         if (threadIdx.x == 0) {
             s_n = 0;
             s_nrew = 0;
         }
         __syncthreads();
     }
-    if (Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
+    if (!FULL && Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
         __shared__ uint32_t s_base;
         __syncthreads();
         const uint32_t nh = s_hits;
@@ -1290,10 +1372,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         }
     }
     if (threadIdx.x == 0) {
-        P.work_cnt[blockIdx.x] = s_hits;
+        if (!FULL) P.work_cnt[blockIdx.x] = s_hits;
         if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
     }
-    if (INLINE) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    YB_SCAN_STAMP(4);
+    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    YB_SCAN_STAMP(7);
 }
 
 // ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
@@ -1432,10 +1516,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_apply_skip(ApplySkipParams Q) {
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b);
     const uint32_t mk = C.mk;
-    const uint32_t ha = sig_bit(C.a), hb = sig_bit(C.b), hp = pair_bit(C.self);
-    const uint32_t *sa = P.sig + (size_t)(ha >> 5) * P.sig_stride;
-    const uint32_t *sb = P.sig + (size_t)(hb >> 5) * P.sig_stride;
-    const uint32_t *sp = P.sig + (size_t)(TOK_WORDS + (hp >> 5)) * P.sig_stride;
+    const SigProbe probe = sig_probe(P.sig, P.sig_stride, C.self);
     agg_init(C.agg);
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     WaveLds &W = s_w[wib];
@@ -1459,7 +1540,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_apply_skip(ApplySkipParams Q) {
         bool maybe = false;
         if (t < P.n_tiles) {
             len = P.tile_len[t];
-            maybe = len != 0 && ((sa[t] >> (ha & 31)) & (sb[t] >> (hb & 31)) & (sp[t] >> (hp & 31)) & 1u);
+            maybe = len != 0 && probe.maybe(t);
         }
         const unsigned long long m = __ballot(maybe);
         uint32_t base = 0;
