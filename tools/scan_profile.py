@@ -24,7 +24,7 @@ with _native.Context() as g:
             out = np.zeros(NB * 8, dtype=np.uint64)
             _native.lib().yabpe_debug_scan_profile(ctypes.c_void_p(out.ctypes.data), ctypes.c_uint32(NB))
             p = out.reshape(NB, 8).astype(np.int64)
-            n256 = (st["n_tiles"] + 255) // 256; target = 1024
+            n256 = (st["n_tiles"] + 255) // 256; target = 768 if m >= 4000 else 1024  # (full_skip_blocks once merges are sparse)
             kt = min(4, max(1, -(-n256 // target)))
             n_scan = min(-(-st["n_tiles"] // (256 * kt)), target)
             recent = p[:, 7].max() - 30000  # stamps older than 300 us belong to earlier launches
@@ -41,7 +41,16 @@ with _native.Context() as g:
             for nm, (a, b) in zip(names, idx):
                 d = us(scan[:, b] - scan[:, a])
                 print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            w0 = scan[(scan[:, 5] > scan[:, 2]) & (scan[:, 6] > scan[:, 5])]  # wave 0 had a rewrite in this launch
+            if len(w0):
+                for nm, (a, b) in (("wave 0: reload arrives", (2, 5)), ("wave 0: first rewrite", (5, 6))):
+                    d = us(w0[:, b] - w0[:, a])
+                    print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us  (n={len(w0)})")
             d = us(scan[:, 7] - scan[:, 0])
             print(f"  {'whole block':28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            ss = (ctypes.c_uint64 * 8)(); _native.lib().yabpe_debug_ss_profile(ss); ss = list(ss)
+            if ss[0]:
+                print("  single_site_tile cycles/tile (workgroup 7, cumulative over the run): neighbours %.0f, deltas->LDS %.0f, sig bits %.0f, compaction+stores %.0f  (n=%d)"
+                      % (ss[1] / ss[0], ss[2] / ss[0], ss[3] / ss[0], ss[4] / ss[0], ss[0]))
             for k in (1, 2, 3, 4, 7):
                 print(f"  stamp {k}: min {us(scan[:,k].min()-t0):7.2f} max {us(scan[:,k].max()-t0):7.2f}")

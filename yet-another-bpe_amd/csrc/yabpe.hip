@@ -155,6 +155,7 @@ struct yabpe_ctx {
     bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
     // candidate argmax
     CandState *cand_state = nullptr;
+    uint32_t *sel_ticket = nullptr;  // k_argmax_cand: finished-workgroup counter (the last one selects; resets itself)
     uint32_t *cand = nullptr;
     bool use_cand = false;
     uint64_t cand_rebuilds = 0, cand_rescans = 0;
@@ -298,6 +299,10 @@ int cand_attach(yabpe_ctx *c) {
     }
     HIPCHK(c, hipMemsetAsync(t.touched, 0, words * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
+    if (!c->sel_ticket) {
+        TRY(dmalloc(c, &c->sel_ticket, 1));
+        HIPCHK(c, hipMemsetAsync(c->sel_ticket, 0, 4, c->stream));
+    }
     if (!c->cand_state) {
         TRY(dmalloc(c, &c->cand_state, 1));
         TRY(dmalloc(c, &c->cand, CAND_CAP));
@@ -314,7 +319,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
     CandState h{best_count - best_count / 5, 0u, 0u};
     HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    CandParams P{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand};
+    CandParams P{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, nullptr, SelectParams{}};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
     hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
     HIPCHK(c, hipGetLastError());
@@ -729,6 +734,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->work_dense);
     dfree(c->blk_read);
     dfree(c->cand_state);
+    dfree(c->sel_ticket);
     dfree(c->cand);
     table_free(c->delta);
     dfree(c->xsend);
@@ -1007,20 +1013,22 @@ static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
 }
 
 static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev) {
-    uint32_t n_part = c->n_partials;
-    if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
-        n_part = std::min<uint32_t>(c->n_partials_cap, 64);
-        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand};
-        hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
-    } else {
-        ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
-        hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
-    }
+    uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64) : c->n_partials;
     SelectParams S{c->partials, n_part, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
                    c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
                    c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u),
                    c->use_cand ? c->cand_state : nullptr};
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
+    bool selected = false;
+    if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
+        const bool fuse = optv(c, "fuse_select", 1) != 0;
+        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, fuse ? c->sel_ticket : nullptr, S};
+        hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
+        selected = fuse;
+    } else {
+        ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
+        hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
+    }
+    if (!selected) hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
     RankParams R{c->tt, c->st};
     const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
     // lexrank maintenance rides on the k_scan_skip launch when that form is used (one dependent launch fewer)
@@ -1486,6 +1494,9 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
 }
 
 #ifdef YB_PROFILE_SCAN
+int yabpe_debug_ss_profile(unsigned long long out[8]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_ss_prof), 64) == hipSuccess ? 0 : -1;
+}
 int yabpe_debug_scan_profile(unsigned long long *out, uint32_t n_blocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_scan_prof), (size_t)std::min<uint32_t>(n_blocks, yb::MAX_LISTS_PROF) * 64) == hipSuccess ? 0 : -1;
 }

@@ -90,6 +90,22 @@ struct Best {
     uint32_t pad;
 };
 
+// A Best record handed from one workgroup to another INSIDE a kernel (k_argmax_cand's last workgroup selects): stored
+// and loaded with device-scope accesses, which are coherent across the XCDs' L2s without a cache write-back.
+__device__ __forceinline__ void best_store_coherent(Best *p, const Best &b) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    __hip_atomic_store(q + 0, b.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, ((unsigned long long)b.key << 32) | b.rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, (unsigned long long)b.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Best best_load_coherent(const Best *p) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<Best *>(p));
+    const unsigned long long a = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return Best{a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)c, 0u};
+}
+
 // candidate argmax state (see k_argmax_cand)
 struct CandState {
     unsigned long long T;
@@ -628,6 +644,17 @@ __device__ __forceinline__ uint32_t tile_elem_uniform(const TileRegs &r, int q) 
     return (e & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+#ifdef YB_PROFILE_SCAN
+__device__ unsigned long long g_ss_prof[8];
+#define YB_SS_STAMP(i)                                                          \
+    do {                                                                        \
+        const unsigned long long t_now = __builtin_readcyclecounter();          \
+        if (lane == 0 && blockIdx.x == 7) atomicAdd(&g_ss_prof[i], t_now - t_ss);                  \
+        t_ss = __builtin_readcyclecounter();                                    \
+    } while (0)
+#else
+#define YB_SS_STAMP(i) do { } while (0)
+#endif
 // The common case of the rewrite (flat layout, a != b): the tile holds exactly ONE site.  Everything is wave-uniform:
 // the site and its neighbours come out of the registers with v_readlane, the four deltas go through the key memo, and
 // the compaction is a funnel shift in registers -- the slots that leave the tile are one contiguous run (the b, or the
@@ -641,12 +668,17 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     DevState *st = C.st;
     const uint32_t a = C.a, b = C.b, c = C.c;
     const int lane = C.lane;
+#ifdef YB_PROFILE_SCAN
+    unsigned long long t_ss = __builtin_readcyclecounter();
+    if (lane == 0 && blockIdx.x == 7) atomicAdd(&g_ss_prof[0], 1ull);
+#endif
     const int j = __ffs((int)mm_s) - 1;
     const int p = j < 8 ? lane_s * 8 + j : 512 + lane_s * 8 + (j - 8); // the site (wave-uniform)
     const uint32_t L = tile_elem_uniform(r, p - 1), R = tile_elem_uniform(r, p + 2);
     const bool left = L < YB_PAD, right = R < YB_PAD;
     const bool dead = !left && R == YB_SEP; // the word was exactly (a b): it leaves the stream (yb_site_word_dies)
 
+    YB_SS_STAMP(1);
     // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1
     auto upd = [&](uint32_t key, int sign, int role) {
         uint32_t slot;
@@ -674,10 +706,12 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         upd(yb_pairkey(b, R), -1, 2);
         upd(yb_pairkey(c, R), +1, 3);
     }
+    YB_SS_STAMP(2);
     if (P.sig && lane == 0 && !dead) {
         if (left) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(L, c));
         if (right) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(c, R));
     }
+    YB_SS_STAMP(3);
 
     // ---- compaction in registers
     const int D0 = dead ? p : p + 1; // first slot that leaves
@@ -729,6 +763,7 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         if (g0 + 8 > p && (uint32_t)g0 < pad_end) wb[(seg ? 64 : 0) + lane] = o; // groups from the first changed slot on
     }
     if (lane == 0) P.tile_len[tile] = new_len;
+    YB_SS_STAMP(4);
     wave_sites += 1;
     wave_freed += (unsigned long long)s;
 }
@@ -1337,6 +1372,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
                 const unsigned long long holders = __ballot(mine != 0);
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
+#ifdef YB_PROFILE_SCAN
+                if (k == (uint32_t)WPB) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
+#endif
                 bool handled = false;
                 if constexpr (INLINE) {
                     if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
@@ -1350,6 +1388,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
                 } else if (lane == 0) {
                     my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
                 }
+#ifdef YB_PROFILE_SCAN
+                if (k == (uint32_t)WPB) YB_SCAN_STAMP(6);
+#endif
             }
             __syncthreads();
         }
@@ -1791,7 +1832,9 @@ struct FoldParams {
 __global__ __launch_bounds__(BLOCK) void k_fold_stats(FoldParams P) { fold_block_stats(P.st, P.blk_stats, P.n_blk); }
 
 
-__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
+// One workgroup: commits a pending halt, folds the apply pass's counters, reduces the argmax partials, applies the
+// stop rules and creates the merged token.  Runs as k_select, or as the tail of k_argmax_cand in its last workgroup.
+__device__ __forceinline__ void select_body(const SelectParams &P) {
     __shared__ Best s_b[BLOCK];
     __shared__ uint32_t s_flag, s_x, s_y, s_lx, s_L, s_pu, s_slot, s_cand, s_eq;
     DevState *st = P.st;
@@ -1810,8 +1853,10 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
     fold_block_stats(st, P.blk_stats, P.n_blk);
     if (s_flag) return;
     Best best{0ull, 0u, EMPTY, 0u, 0u};
-    for (uint32_t i = tid; i < P.n_partials; i += BLOCK)
-        if (best_gt(P.partials[i], best)) best = P.partials[i];
+    for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
+        const Best e = best_load_coherent(&P.partials[i]);
+        if (best_gt(e, best)) best = e;
+    }
     s_b[tid] = best;
     __syncthreads();
     for (int o = BLOCK / 2; o >= 1; o >>= 1) {
@@ -1825,7 +1870,8 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         if (it > P.rec_base && st->sites) P.rec_sites[it - 1 - P.rec_base] = st->sites; // (0: already closed, this is a re-run)
         st->tokens_now -= st->sites;
         st->sites = 0;
-        if (P.cs && it < st->num_merges && (best.cnt < P.cs->T || P.cs->overflow)) {
+        if (P.cs && it < st->num_merges &&
+            (best.cnt < P.cs->T || __hip_atomic_load(&P.cs->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             // the candidate set no longer proves that this is the maximum: the host redoes this merge with a full scan
             st->halt = HALT_RESCAN;
             s_flag = 1;
@@ -1922,6 +1968,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) {
         st->iter = it + 1;
     }
 }
+__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P); }
 
 // ================================================================ loading words into tiles
 struct LoadParams {
@@ -2040,6 +2087,8 @@ struct CandParams {
     DevState *st;
     CandState *cs;
     uint32_t *cand;
+    uint32_t *ticket;  // != NULL: the last workgroup to finish runs the selection itself (no k_select launch)
+    SelectParams sel;
 };
 
 __device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best &best) {
@@ -2053,39 +2102,54 @@ __device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best 
 
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     __shared__ Best s_b[WPB];
-    if (P.st->done | P.st->halt) return;
-    Best best{0ull, 0u, EMPTY, 0u, 0u};
-    const unsigned long long T = P.cs->T;
-    const uint32_t n0 = min(P.cs->n, CAND_CAP);
-    const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
-    for (uint32_t i = tid; i < n0; i += nth) cand_eval(P, P.cand[i], best);
-    const uint32_t words = (P.table.cap + 31) >> 5;
-    for (uint32_t w = tid; w < words; w += nth) {
-        uint32_t bits = P.table.touched[w];
-        if (!bits) continue;
-        P.table.touched[w] = 0u;
-        while (bits) {
-            const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
-            bits &= bits - 1;
-            cand_eval(P, s, best);
-            if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
-                const uint32_t bit = 1u << (s & 31);
-                if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
-                    const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-                    if (idx < CAND_CAP) P.cand[idx] = s; else P.cs->overflow = 1u;
+    __shared__ uint32_t s_last;
+    if (!(P.st->done | P.st->halt)) {
+        Best best{0ull, 0u, EMPTY, 0u, 0u};
+        const unsigned long long T = P.cs->T;
+        const uint32_t n0 = min(P.cs->n, CAND_CAP);
+        const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
+        for (uint32_t i = tid; i < n0; i += nth) cand_eval(P, P.cand[i], best);
+        const uint32_t words = (P.table.cap + 31) >> 5;
+        for (uint32_t w = tid; w < words; w += nth) {
+            uint32_t bits = P.table.touched[w];
+            if (!bits) continue;
+            P.table.touched[w] = 0u;
+            while (bits) {
+                const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
+                bits &= bits - 1;
+                cand_eval(P, s, best);
+                if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
+                    const uint32_t bit = 1u << (s & 31);
+                    if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
+                        const uint32_t idx = atomicAdd(&P.cs->n, 1u);
+                        if (idx < CAND_CAP) P.cand[idx] = s; else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
+        best = best_wave_reduce(best);
+        const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+        if (lane == 0) s_b[wib] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < WPB; ++i)
+                if (best_gt(s_b[i], best)) best = s_b[i];
+            best_store_coherent(&P.partials[blockIdx.x], best);
+        }
     }
-    best = best_wave_reduce(best);
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    if (lane == 0) s_b[wib] = best;
+    if (!P.ticket) return;
+    // The workgroup that finishes last does the selection.  No __threadfence (an L2 write-back on this part): what
+    // the selection reads from THIS kernel -- the partials and the overflow flag -- goes through device-scope
+    // accesses; each workgroup waits for its own to be acknowledged before it takes its ticket.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < WPB; ++i)
-            if (best_gt(s_b[i], best)) best = s_b[i];
-        P.partials[blockIdx.x] = best;
+        s_last = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    select_body(P.sel);
 }
 
 // cand = every slot with count >= cs->T (the bitmaps were cleared by the host)
