@@ -52,5 +52,9 @@ with _native.Context() as g:
             if ss[0]:
                 print("  single_site_tile cycles/tile (workgroup 7, cumulative over the run): neighbours %.0f, deltas->LDS %.0f, sig bits %.0f, compaction+stores %.0f  (n=%d)"
                       % (ss[1] / ss[0], ss[2] / ss[0], ss[3] / ss[0], ss[4] / ss[0], ss[0]))
+            sp = (ctypes.c_uint64 * 16)(); _native.lib().yabpe_debug_sel_profile(sp); sp = [int(v) for v in sp]
+            rel = lambda i: (sp[i] - sp[0]) / 100.0
+            print("  k_argmax_cand+select (last launch): wg0 partial stored %.2f | last ticket %.2f | loads in %.2f | winner decided %.2f | len/off %.2f | bytes+hash %.2f | probe %.2f | end %.2f us"
+                  % (rel(9), rel(1), rel(2), rel(3), rel(4), rel(5), rel(6), rel(7)))
             for k in (1, 2, 3, 4, 7):
                 print(f"  stamp {k}: min {us(scan[:,k].min()-t0):7.2f} max {us(scan[:,k].max()-t0):7.2f}")

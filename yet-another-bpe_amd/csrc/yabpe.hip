@@ -135,7 +135,7 @@ struct yabpe_ctx {
     unsigned long long *scratch64 = nullptr;  // 16 x u64: [0] live sum [1] freq overflow [2,3] long words [4,5,6] verify/checksum
                                               // [7] comm_max [8] exchange record count [9] local count-table entries
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
-    uint32_t blk_used = 0;                    // largest grid that wrote blk_stats
+    uint32_t blk_used = 0;                    // largest grid that wrote blk_stats since they were last folded
     // split apply: worklist of tiles that contain the pair
     uint2 *work = nullptr;
     uint32_t *work_cnt = nullptr;
@@ -340,6 +340,7 @@ int fold_stats(yabpe_ctx *c) {
     FoldParams F{c->st, c->blk_stats, std::max(c->blk_used, 1u)};
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(BLOCK), 0, c->stream, F);
     HIPCHK(c, hipGetLastError());
+    c->blk_used = 0;
     return 0;
 }
 
@@ -1018,6 +1019,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                    c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
                    c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u),
                    c->use_cand ? c->cand_state : nullptr};
+    c->blk_used = 0;  // the selection folds and clears them; what follows counts this merge's grids
     bool selected = false;
     if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
         const bool fuse = optv(c, "fuse_select", 1) != 0;
@@ -1494,6 +1496,9 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
 }
 
 #ifdef YB_PROFILE_SCAN
+int yabpe_debug_sel_profile(unsigned long long out[16]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_sel_prof), 128) == hipSuccess ? 0 : -1;
+}
 int yabpe_debug_ss_profile(unsigned long long out[8]) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_ss_prof), 64) == hipSuccess ? 0 : -1;
 }

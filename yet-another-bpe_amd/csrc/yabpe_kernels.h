@@ -210,8 +210,7 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
         if (k == key) {
             atomicAdd(&t.cnt[s], (unsigned long long)d);
             if (d > 0 && t.touched) { // a count went up: the candidate argmax must look at this slot again
-                const uint32_t bit = 1u << (s & 31);
-                if (!(t.touched[s >> 5] & bit)) atomicOr(&t.touched[s >> 5], bit);
+                atomicOr(&t.touched[s >> 5], 1u << (s & 31)); // (no test first: that would be one more round trip)
             }
             return;
         }
@@ -679,37 +678,25 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     const bool dead = !left && R == YB_SEP; // the word was exactly (a b): it leaves the stream (yb_site_word_dies)
 
     YB_SS_STAMP(1);
-    // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1
-    auto upd = [&](uint32_t key, int sign, int role) {
-        uint32_t slot;
-        if (C.memo.key[role] == key) {
-            slot = C.memo.slot[role];
-        } else {
-            uint32_t sl = 0;
-            if (lane == 0) sl = agg_slot(C.agg, key);
-            slot = __builtin_amdgcn_readfirstlane(sl);
-            C.memo.key[role] = key;
-            C.memo.slot[role] = slot;
-        }
-        if (lane == 0) {
-            if (slot < (uint32_t)AGG_N)
-                atomicAdd(&C.agg.vals[slot], (AggV)sign);
-            else
-                gt_add(P.out, st, key, (long long)sign);
-        }
-    };
-    if (left) {
-        upd(yb_pairkey(L, a), -1, 0);
-        upd(yb_pairkey(L, c), +1, 1);
-    }
-    if (right) {
-        upd(yb_pairkey(b, R), -1, 2);
-        upd(yb_pairkey(c, R), +1, 3);
+    // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1, one per lane: the four
+    // aggregator probes run side by side instead of one after the other
+    {
+        const uint32_t kl = lane & 1 ? yb_pairkey(L, c) : yb_pairkey(L, a);
+        const uint32_t kr = lane & 1 ? yb_pairkey(c, R) : yb_pairkey(b, R);
+        const bool on = lane < 4 && (lane < 2 ? left : right);
+        if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
     }
     YB_SS_STAMP(2);
-    if (P.sig && lane == 0 && !dead) {
-        if (left) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(L, c));
-        if (right) sig_set_pair(P.sig, P.sig_stride, tile, yb_pairkey(c, R));
+    // the two pairs this site creates are now present in the tile: 2 x SIG_K signature bits, one per lane
+    if (P.sig && !dead && lane < 2 * SIG_K) {
+        const bool second = lane >= SIG_K;
+        if (second ? right : left) {
+            const SigHash H = sig_hash(second ? yb_pairkey(c, R) : yb_pairkey(L, c));
+            const int k = lane - (second ? SIG_K : 0);
+            const uint32_t row = k == 0 ? H.row[0] : k == 1 ? H.row[1] : H.row[2];
+            const uint32_t bit = k == 0 ? H.bit[0] : k == 1 ? H.bit[1] : H.bit[2];
+            atomicOr(&P.sig[(size_t)row * P.sig_stride + tile], 1u << bit);
+        }
     }
     YB_SS_STAMP(3);
 
@@ -724,6 +711,7 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     const uint32_t fz = __builtin_amdgcn_readfirstlane(r.vb.z);
 #pragma unroll
     for (int seg = 0; seg < 2; ++seg) {
+        if (seg == 0 && p >= 512) continue; // the site and everything that moves is in segment B (uniform)
         const int g0 = seg ? 512 + lane * 8 : lane * 8;
         const uint4 v = seg ? r.vb : r.va;
         // window of 7 dwords: own 4 + the next group's first 3 (enough for s <= 3)
@@ -1105,6 +1093,18 @@ YB_HD uint32_t yb_tok_hash(const uint8_t *p, uint32_t n) {
     uint32_t m = n < 16u ? n : 16u;
     for (uint32_t i = 0; i < m; ++i) h = (h ^ p[i]) * 16777619u;
     for (uint32_t i = 0; i < m; ++i) h = (h ^ p[n - 1 - i]) * 16777619u;
+    h ^= h >> 15;
+    h *= 0x2c1b3c6dU;
+    h ^= h >> 12;
+    return h;
+}
+
+// The same hash from the token's two ends: ends[k] = p[k], ends[16 + k] = p[n - 1 - k], k < min(n, 16).
+__device__ __forceinline__ uint32_t yb_tok_hash_ends(const uint8_t *ends, uint32_t n) {
+    uint32_t h = 2166136261u ^ n;
+    const uint32_t m = n < 16u ? n : 16u;
+    for (uint32_t i = 0; i < m; ++i) h = (h ^ ends[i]) * 16777619u;
+    for (uint32_t i = 0; i < m; ++i) h = (h ^ ends[16u + i]) * 16777619u;
     h ^= h >> 15;
     h *= 0x2c1b3c6dU;
     h ^= h >> 12;
@@ -1733,18 +1733,61 @@ __device__ __forceinline__ bool best_gt(const Best &x, const Best &y) {
     return x.cnt > y.cnt || (x.cnt == y.cnt && x.rk > y.rk);
 }
 
+// Maximum of (cnt, rk) over the wave with DPP moves only (six steps of the row_shr / row_bcast ladder leave it in lane 63;
+// a lane without a source keeps its own value).  rk is unique per pair, so the winner's lane is found with one ballot and
+// its key / slot are read out of it.  Returns the same record in every lane.
 __device__ __forceinline__ Best best_wave_reduce(Best v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        Best u;
-        u.cnt = __shfl_xor(v.cnt, o);
-        u.rk = __shfl_xor(v.rk, o);
-        u.key = __shfl_xor(v.key, o);
-        u.slot = __shfl_xor(v.slot, o);
-        u.pad = 0;
-        if (best_gt(u, v)) v = u;
+    uint32_t hi = (uint32_t)(v.cnt >> 32), lo = (uint32_t)v.cnt, rk = v.rk;
+#define YB_BEST_STEP(ctrl, rowmask)                                                                          \
+    {                                                                                                        \
+        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, ctrl, rowmask, 0xf, false); \
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, ctrl, rowmask, 0xf, false); \
+        const uint32_t r2 = (uint32_t)__builtin_amdgcn_update_dpp((int)rk, (int)rk, ctrl, rowmask, 0xf, false); \
+        const bool g = h2 > hi || (h2 == hi && (l2 > lo || (l2 == lo && r2 > rk)));                          \
+        hi = g ? h2 : hi;                                                                                    \
+        lo = g ? l2 : lo;                                                                                    \
+        rk = g ? r2 : rk;                                                                                    \
     }
-    return v;
+    YB_BEST_STEP(0x111, 0xf) // row_shr:1
+    YB_BEST_STEP(0x112, 0xf) // row_shr:2
+    YB_BEST_STEP(0x114, 0xf) // row_shr:4
+    YB_BEST_STEP(0x118, 0xf) // row_shr:8
+    YB_BEST_STEP(0x142, 0xa) // row_bcast:15 -> rows 1, 3
+    YB_BEST_STEP(0x143, 0xc) // row_bcast:31 -> rows 2, 3
+#undef YB_BEST_STEP
+    const uint32_t mh = __builtin_amdgcn_readlane(hi, 63), ml = __builtin_amdgcn_readlane(lo, 63);
+    const uint32_t mr = __builtin_amdgcn_readlane(rk, 63);
+    const unsigned long long mc = ((unsigned long long)mh << 32) | ml;
+    const unsigned long long who = __ballot(v.cnt == mc && v.rk == mr);
+    const int src = __ffsll((long long)who) - 1; // never empty: the maximum is some lane's value
+    Best r;
+    r.cnt = mc;
+    r.rk = mr;
+    r.key = __builtin_amdgcn_readlane(v.key, src);
+    r.slot = __builtin_amdgcn_readlane(v.slot, src);
+    r.pad = 0;
+    return r;
+}
+
+// Sum of a 64-bit value over the wave, same ladder (a lane without a source adds 0); every lane gets the total.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+#define YB_SUM_STEP(ctrl, rowmask, bc)                                                                     \
+    {                                                                                                      \
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rowmask, 0xf, bc);      \
+        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rowmask, 0xf, bc);      \
+        const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)h2 << 32) | l2); \
+        lo = (uint32_t)t;                                                                                  \
+        hi = (uint32_t)(t >> 32);                                                                          \
+    }
+    YB_SUM_STEP(0x111, 0xf, true)
+    YB_SUM_STEP(0x112, 0xf, true)
+    YB_SUM_STEP(0x114, 0xf, true)
+    YB_SUM_STEP(0x118, 0xf, true)
+    YB_SUM_STEP(0x142, 0xa, false)
+    YB_SUM_STEP(0x143, 0xc, false)
+#undef YB_SUM_STEP
+    return ((unsigned long long)__builtin_amdgcn_readlane(hi, 63) << 32) | __builtin_amdgcn_readlane(lo, 63);
 }
 
 struct ArgmaxParams {
@@ -1832,82 +1875,150 @@ struct FoldParams {
 __global__ __launch_bounds__(BLOCK) void k_fold_stats(FoldParams P) { fold_block_stats(P.st, P.blk_stats, P.n_blk); }
 
 
+#ifdef YB_PROFILE_SCAN
+__device__ unsigned long long g_sel_prof[16];
+#define YB_SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_prof[i] = wall_clock64(); } while (0)
+#else
+#define YB_SEL_STAMP(i) do { } while (0)
+#endif
 // One workgroup: commits a pending halt, folds the apply pass's counters, reduces the argmax partials, applies the
 // stop rules and creates the merged token.  Runs as k_select, or as the tail of k_argmax_cand in its last workgroup.
+// This is a chain of dependent memory round trips on the critical path of every merge, so it is kept short: thread 0
+// works on a register copy of DevState (one load of the whole struct, one store at the end), and everything that does
+// not depend on the winner (DevState, block counters, partials) is requested in the same round.
 __device__ __forceinline__ void select_body(const SelectParams &P) {
-    __shared__ Best s_b[BLOCK];
-    __shared__ uint32_t s_flag, s_x, s_y, s_lx, s_L, s_pu, s_slot, s_cand, s_eq;
+    __shared__ Best s_b[WPB];
+    __shared__ uint32_t s_flag, s_x, s_y, s_pu, s_slot, s_cand, s_eq, s_lo[4];
+    __shared__ unsigned long long s_fold[2];
+    __shared__ uint8_t s_ends[32];
     DevState *st = P.st;
     const int tid = threadIdx.x;
+    YB_SEL_STAMP(1);
+    DevState d; // thread 0 only
+    unsigned long long candT = 0;
+    uint32_t cand_over = 0;
     if (tid == 0) {
-        if (st->halt == 0 && st->halt_req != 0) st->halt = st->halt_req;
-        // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
-        // no replica can run out of probes on its own.
-        if (st->halt == 0 && st->table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) st->halt = HALT_TABLE_FULL; // > 80 % full
-        if (P.delta_hdr) P.delta_hdr->count = 0ull;
-        for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
-        st->work_total = 0u;
-        s_flag = st->done | st->halt;
+        d = *st;
+        if (P.cs) {
+            candT = P.cs->T;
+            cand_over = __hip_atomic_load(&P.cs->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_fold[0] = 0;
+        s_fold[1] = 0;
+        s_flag = 0;
     }
-    __syncthreads();
-    fold_block_stats(st, P.blk_stats, P.n_blk);
-    if (s_flag) return;
+    // counters of the last apply pass (plain stores by its workgroups), summed and cleared
+    unsigned long long fa = 0, ff = 0;
+    {
+        ulonglong2 *bs = reinterpret_cast<ulonglong2 *>(P.blk_stats);
+        for (uint32_t i0 = 0; i0 < P.n_blk; i0 += 4 * BLOCK) { // four loads in flight, then the four clears
+            ulonglong2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k * BLOCK + tid;
+                v[k] = i < P.n_blk ? bs[i] : make_ulonglong2(0ull, 0ull);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k * BLOCK + tid;
+                fa += v[k].x;
+                ff += v[k].y;
+                if (i < P.n_blk && (v[k].x | v[k].y)) bs[i] = make_ulonglong2(0ull, 0ull);
+            }
+        }
+    }
     Best best{0ull, 0u, EMPTY, 0u, 0u};
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
         const Best e = best_load_coherent(&P.partials[i]);
         if (best_gt(e, best)) best = e;
     }
-    s_b[tid] = best;
-    __syncthreads();
-    for (int o = BLOCK / 2; o >= 1; o >>= 1) {
-        if (tid < o && best_gt(s_b[tid + o], s_b[tid])) s_b[tid] = s_b[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        best = s_b[0];
-        // close the log entry of the previous iteration
-        const uint32_t it = st->iter;
-        if (it > P.rec_base && st->sites) P.rec_sites[it - 1 - P.rec_base] = st->sites; // (0: already closed, this is a re-run)
-        st->tokens_now -= st->sites;
-        st->sites = 0;
-        if (P.cs && it < st->num_merges &&
-            (best.cnt < P.cs->T || __hip_atomic_load(&P.cs->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            // the candidate set no longer proves that this is the maximum: the host redoes this merge with a full scan
-            st->halt = HALT_RESCAN;
-            s_flag = 1;
-        } else
-        // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
-        if (it >= st->num_merges || best.cnt == 0 || best.cnt < st->min_freq) {
-            st->done = 1;
-            s_flag = 1;
-        } else {
-            const uint32_t x = best.key >> 16, y = best.key & 0xffffu;
-            const uint32_t lx = P.tt.len[x], ly = P.tt.len[y];
-            if ((unsigned long long)st->pool_used + lx + ly > P.tt.pool_cap) {
-                st->halt = HALT_POOL_FULL;
-                s_flag = 1;
-            }
-            s_x = x;
-            s_y = y;
-            s_lx = lx;
-            s_L = lx + ly;
-            s_pu = st->pool_used;
+    fa = wave_sum_u64(fa);
+    ff = wave_sum_u64(ff);
+    best = best_wave_reduce(best);
+    __syncthreads(); // s_fold zeroed
+    if ((tid & 63) == 0) {
+        s_b[tid >> 6] = best;
+        if (fa | ff) {
+            atomicAdd(&s_fold[0], fa);
+            atomicAdd(&s_fold[1], ff);
         }
     }
     __syncthreads();
+    YB_SEL_STAMP(2);
+    if (tid == 0) {
+        if (P.delta_hdr) P.delta_hdr->count = 0ull;
+        if (d.halt == 0 && d.halt_req != 0) d.halt = d.halt_req;
+        // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
+        // no replica can run out of probes on its own.
+        if (d.halt == 0 && d.table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d.halt = HALT_TABLE_FULL; // > 80 % full
+        for (int q = 0; q < 8; ++q) d.chunk_next[q] = 0u;
+        d.work_total = 0u;
+        d.sites += s_fold[0];
+        d.live_slots -= s_fold[1];
+        if (d.done | d.halt) {
+            s_flag = 1;
+        } else {
+            for (int w = 1; w < WPB; ++w)
+                if (best_gt(s_b[w], best)) best = s_b[w];
+            s_b[0] = best;
+            // close the log entry of the previous iteration
+            const uint32_t it = d.iter;
+            if (it > P.rec_base && d.sites) P.rec_sites[it - 1 - P.rec_base] = d.sites; // (0: already closed, this is a re-run)
+            d.tokens_now -= d.sites;
+            d.sites = 0;
+            if (P.cs && it < d.num_merges && (best.cnt < candT || cand_over)) {
+                // the candidate set no longer proves that this is the maximum: the host redoes this merge with a full scan
+                d.halt = HALT_RESCAN;
+                s_flag = 1;
+            } else if (it >= d.num_merges || best.cnt == 0 || best.cnt < d.min_freq) {
+                // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
+                d.done = 1;
+                s_flag = 1;
+            } else {
+                s_x = best.key >> 16;
+                s_y = best.key & 0xffffu;
+                s_pu = d.pool_used;
+            }
+        }
+        if (s_flag) *st = d;
+    }
+    __syncthreads();
     if (s_flag) return;
-    const uint32_t x = s_x, y = s_y, lx = s_lx, L = s_L, pu = s_pu;
-    // merged = p0 + p1 (trainer.py:251), written at the end of the pool
+    YB_SEL_STAMP(3);
+    // the two tokens' lengths and offsets: four loads side by side, then one round of byte loads
+    if (tid < 2) {
+        const uint32_t t = tid ? s_y : s_x;
+        s_lo[tid] = P.tt.len[t];
+        s_lo[2 + tid] = P.tt.off[t];
+    }
+    __syncthreads();
+    YB_SEL_STAMP(4);
+    const uint32_t x = s_x, y = s_y, lx = s_lo[0], L = s_lo[0] + s_lo[1], pu = s_pu;
+    if ((unsigned long long)pu + L > P.tt.pool_cap) {
+        if (tid == 0) {
+            d.halt = HALT_POOL_FULL;
+            *st = d;
+        }
+        return;
+    }
+    // merged = p0 + p1 (trainer.py:251), written at the end of the pool; its first / last 16 bytes also go to LDS,
+    // where the hash is computed without further trips to memory
     uint8_t *mp = P.tt.pool + pu;
     {
-        const uint8_t *px = P.tt.pool + P.tt.off[x], *py = P.tt.pool + P.tt.off[y];
-        for (uint32_t i = tid; i < L; i += BLOCK) mp[i] = i < lx ? px[i] : py[i - lx];
+        const uint8_t *px = P.tt.pool + s_lo[2], *py = P.tt.pool + s_lo[3];
+        for (uint32_t i = tid; i < L; i += BLOCK) {
+            const uint8_t v = i < lx ? px[i] : py[i - lx];
+            mp[i] = v;
+            if (i < 16u) s_ends[i] = v;
+            if (L - 1u - i < 16u) s_ends[16u + (L - 1u - i)] = v; // s_ends[16 + k] = merged[L - 1 - k]
+        }
     }
     __threadfence_block();
     __syncthreads();
     // "merged not in vocab" (trainer.py:298): probe the byte-string set
-    if (tid == 0) s_slot = yb_tok_hash(mp, L) & P.tt.vset_mask;
+    if (tid == 0) s_slot = yb_tok_hash_ends(s_ends, L) & P.tt.vset_mask;
     __syncthreads();
+    YB_SEL_STAMP(5);
     uint32_t found = EMPTY;
     while (true) {
         if (tid == 0) {
@@ -1932,41 +2043,44 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
         if (tid == 0) s_slot = (s_slot + 1) & P.tt.vset_mask;
         __syncthreads();
     }
+    YB_SEL_STAMP(6);
     if (tid == 0) {
         uint32_t cid;
         uint32_t is_new = 0;
         if (found != EMPTY) {
             cid = found; // bytes already a token: no id is consumed (trainer.py:298-300)
-        } else if (st->n_tokens >= YB_MAX_TOKENS) {
-            st->halt = HALT_VOCAB_FULL;
+        } else if (d.n_tokens >= YB_MAX_TOKENS) {
+            d.halt = HALT_VOCAB_FULL;
+            *st = d;
             return;
         } else {
-            cid = st->n_tokens;
+            cid = d.n_tokens;
             P.tt.off[cid] = pu;
             P.tt.len[cid] = L;
             P.tt.rank[cid] = 0;
             P.tt.vset[s_slot] = cid;
-            st->pool_used = pu + L;
-            st->n_tokens = cid + 1;
+            d.pool_used = pu + L;
+            d.n_tokens = cid + 1;
             is_new = 1;
         }
-        const uint32_t it = st->iter;
-        const uint32_t ri = it - P.rec_base;
+        const uint32_t ri = d.iter - P.rec_base;
         P.rec_left[ri] = x; // merges.append(best_pair) (trainer.py:296)
         P.rec_right[ri] = y;
         P.rec_merged[ri] = cid;
         P.rec_count[ri] = s_b[0].cnt;
-        P.rec_live_slots[ri] = st->live_slots;
+        P.rec_live_slots[ri] = d.live_slots;
         // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
         // set it here once instead of letting every workgroup subtract its share from one hot address
         P.table.cnt[s_b[0].slot] = 0ull;
-        st->a = x;
-        st->b = y;
-        st->c = cid;
-        st->best_count = s_b[0].cnt;
-        st->c_is_new = is_new;
-        st->iter = it + 1;
+        d.a = x;
+        d.b = y;
+        d.c = cid;
+        d.best_count = s_b[0].cnt;
+        d.c_is_new = is_new;
+        d.iter += 1;
+        *st = d;
     }
+    YB_SEL_STAMP(7);
 }
 __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P); }
 
@@ -2103,6 +2217,10 @@ __device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best 
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     __shared__ Best s_b[WPB];
     __shared__ uint32_t s_last;
+#ifdef YB_PROFILE_SCAN
+    if (blockIdx.x == 0) YB_SEL_STAMP(0);
+    if (blockIdx.x == 0) YB_SEL_STAMP(8);
+#endif
     if (!(P.st->done | P.st->halt)) {
         Best best{0ull, 0u, EMPTY, 0u, 0u};
         const unsigned long long T = P.cs->T;
@@ -2136,6 +2254,9 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
                 if (best_gt(s_b[i], best)) best = s_b[i];
             best_store_coherent(&P.partials[blockIdx.x], best);
         }
+#ifdef YB_PROFILE_SCAN
+        if (blockIdx.x == 0) YB_SEL_STAMP(9);
+#endif
     }
     if (!P.ticket) return;
     // The workgroup that finishes last does the selection.  No __threadfence (an L2 write-back on this part): what
