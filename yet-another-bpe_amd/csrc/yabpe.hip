@@ -1225,7 +1225,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         {
             const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
             const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
-            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < 256.0);
+            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < (double)optv(c, "dense_multi", 2048));
         }
         if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
             c->use_cand = false;
