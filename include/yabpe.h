@@ -31,7 +31,8 @@ enum {
     YABPE_E_HIP = -3,      /* HIP runtime error (message has the call) */
     YABPE_E_CAPACITY = -4, /* a documented limit was hit (token ids are u16: at most 65534 tokens) */
     YABPE_E_INTERNAL = -5, /* device-side invariant violated */
-    YABPE_E_COMM = -6      /* RCCL error */
+    YABPE_E_COMM = -6,     /* RCCL error */
+    YABPE_E_UTF8 = -7      /* yabpe_pretokenize: the text is not valid UTF-8 (position reported) */
 };
 
 /* yabpe_load_words flags */
@@ -141,6 +142,23 @@ int yabpe_synth_free(yabpe_ctx *ctx);
 /* Copy `n` bytes device->host / host->device (for fixtures and the CPU-baseline sample). */
 int yabpe_memcpy_d2h(yabpe_ctx *ctx, void *dst_host, const void *src_dev, uint64_t n);
 int yabpe_memcpy_h2d(yabpe_ctx *ctx, void *dst_dev, const void *src_host, uint64_t n);
+
+/* Pre-tokeniser (the step before the path) -----------------------------------------
+ * Reproduces _preprocess_corpus (trainer.py:136-214) on the device: every chunk [chunk_off[k], chunk_off[k+1]) of `text`
+ * (the last one ends at n_bytes; chunk_off == NULL: one chunk) is decoded as UTF-8 and split with the GPT-2 pattern of
+ * trainer.py:163, preceded by the special tokens in the given order (:165-167), exactly as regex.findall does.  The host
+ * keeps what it does in the reference: reading files and choosing the chunk cuts (:172-198).
+ * Results: *out_dev_text = the text in device memory (`text` itself when it already is a device pointer, else a staged
+ * copy owned by the library) and *out_dev_word_off = n_words + 1 offsets into it (device memory, owned by the library,
+ * released by yabpe_pretokenize_free / yabpe_destroy): pre-token i = text[off[i], off[i+1]).  Both can be passed
+ * straight to yabpe_load_words (no copy; add YABPE_LOAD_DEDUP to pool equal pre-tokens, trainer.py:221-225).
+ * Malformed UTF-8: returns YABPE_E_UTF8 and *out_bad_pos = UnicodeDecodeError.start of the first bad chunk (:156-161).
+ * The character classes (\p{L}, \p{N}, \s) are those of the third-party `regex` module the reference uses
+ * (csrc/unicode_classes.inc, generated by tools/gen_unicode_classes.py). */
+int yabpe_pretokenize(yabpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off, uint32_t n_chunks,
+                      const uint8_t *special_bytes, const uint32_t *special_off, uint32_t n_special,
+                      const uint8_t **out_dev_text, uint64_t **out_dev_word_off, uint64_t *out_n_words, int64_t *out_bad_pos);
+int yabpe_pretokenize_free(yabpe_ctx *ctx);
 
 /* Multi-GPU (one process per GPU; words are sharded by the caller) -----------------
  * Every rank holds its shard of the words and a replica of the pair table.  After each apply pass the ranks

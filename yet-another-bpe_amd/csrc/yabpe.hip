@@ -21,6 +21,8 @@
 #include "../../include/yabpe.h"
 #include "yabpe_kernels.h"
 #include "yabpe_aux_kernels.h"
+#include "yabpe_pretok_kernels.h"
+#include "unicode_classes.inc"
 
 using namespace yb;
 
@@ -131,6 +133,8 @@ struct yabpe_ctx {
     std::vector<EventPair> events;
     // synth buffers
     std::vector<void *> synth_bufs;
+    std::vector<void *> pretok_bufs;          // staged text / word offsets handed out by yabpe_pretokenize
+    uint8_t *pt_cls = nullptr;                // class per code point (unicode_classes.inc expanded), built on first use
     // misc device scratch
     unsigned long long *scratch64 = nullptr;  // 16 x u64: [0] live sum [1] freq overflow [2,3] long words [4,5,6] verify/checksum
                                               // [7] comm_max [8] exchange record count [9] local count-table entries
@@ -723,6 +727,8 @@ void yabpe_destroy(yabpe_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     yabpe_synth_free(c);
+    yabpe_pretokenize_free(c);
+    dfree(c->pt_cls);
     free_corpus(c);
     free_records(c);
     dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rank); dfree(c->tt.vset);
@@ -1542,6 +1548,89 @@ int yabpe_synth_free(yabpe_ctx *c) {
     if (!c) return YABPE_E_INVALID;
     for (void *p : c->synth_bufs) dfree(p);
     c->synth_bufs.clear();
+    return YABPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- pre-tokeniser
+int yabpe_pretokenize(yabpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off, uint32_t n_chunks,
+                      const uint8_t *special_bytes, const uint32_t *special_off, uint32_t n_special,
+                      const uint8_t **out_dev_text, uint64_t **out_dev_word_off, uint64_t *out_n_words, int64_t *out_bad_pos) {
+    if (!c || !out_dev_text || !out_dev_word_off || !out_n_words || !out_bad_pos) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    *out_dev_text = nullptr; *out_dev_word_off = nullptr; *out_n_words = 0; *out_bad_pos = -1;
+    if (n_bytes && !text) return fail(c, YABPE_E_INVALID, "text is NULL");
+    if (n_special > 255) return fail(c, YABPE_E_CAPACITY, "at most 255 special tokens in the pre-tokeniser");
+    if (n_special && (!special_bytes || !special_off)) return fail(c, YABPE_E_INVALID, "special token arrays are NULL");
+    uint32_t max_len = 0;
+    for (uint32_t s = 0; s < n_special; ++s) {
+        if (special_off[s + 1] <= special_off[s])
+            return fail(c, YABPE_E_INVALID, "special token %u is empty (it would match at every position)", s);
+        max_len = std::max(max_len, special_off[s + 1] - special_off[s]);
+    }
+    std::vector<unsigned long long> chunks;
+    if (chunk_off && n_chunks) {
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            if (chunk_off[k] > n_bytes || (k && chunk_off[k] < chunk_off[k - 1])) return fail(c, YABPE_E_INVALID, "chunk offsets must ascend inside the text");
+            chunks.push_back(chunk_off[k]);
+        }
+        if (chunks[0] != 0) return fail(c, YABPE_E_INVALID, "the first chunk must start at 0");
+    } else {
+        chunks.push_back(0);
+    }
+    if (!c->pt_cls) {  // expand the generated runs into one byte per code point
+        std::vector<uint8_t> cls(0x110000, PT_O);
+        for (unsigned r = 0; r < YB_UNICODE_CLASS_NRUNS; ++r) {
+            const unsigned lo = YB_UNICODE_CLASS_RUNS[r][0];
+            const unsigned hi = r + 1 < YB_UNICODE_CLASS_NRUNS ? YB_UNICODE_CLASS_RUNS[r + 1][0] : 0x110000;
+            memset(cls.data() + lo, (int)YB_UNICODE_CLASS_RUNS[r][1], hi - lo);
+        }
+        TRY(dmalloc(c, &c->pt_cls, cls.size()));
+        HIPCHK(c, hipMemcpy(c->pt_cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    }
+    // inputs on the device
+    const uint8_t *d_text = text;
+    void *own_text = nullptr;
+    if (n_bytes && !is_device_ptr(text)) {
+        HIPCHK(c, hipMalloc(&own_text, n_bytes));
+        if (hipMemcpy(own_text, text, n_bytes, hipMemcpyHostToDevice) != hipSuccess) { dfree(own_text); return fail(c, YABPE_E_HIP, "staging the text failed"); }
+        d_text = (const uint8_t *)own_text;
+    }
+    unsigned long long *d_chunks = nullptr;
+    uint8_t *d_spb = nullptr;
+    uint32_t *d_spo = nullptr;
+    auto drop = [&]() { dfree(d_chunks); dfree(d_spb); dfree(d_spo); };
+    if (hipMalloc((void **)&d_chunks, chunks.size() * 8) != hipSuccess ||
+        hipMemcpy(d_chunks, chunks.data(), chunks.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { drop(); dfree(own_text); return fail(c, YABPE_E_HIP, "chunk table"); }
+    PtSpecials sp{nullptr, nullptr, n_special, max_len};
+    if (n_special) {
+        const uint32_t tot = special_off[n_special];
+        if (hipMalloc((void **)&d_spb, tot) != hipSuccess || hipMalloc((void **)&d_spo, (n_special + 1) * 4) != hipSuccess ||
+            hipMemcpy(d_spb, special_bytes, tot, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_spo, special_off, (n_special + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) { drop(); dfree(own_text); return fail(c, YABPE_E_HIP, "special token table"); }
+        sp.bytes = d_spb;
+        sp.off = d_spo;
+    }
+    PretokOut po{};
+    const int r = pretokenize(c->stream, d_text, n_bytes, d_chunks, (uint32_t)chunks.size(), c->pt_cls, sp, &po);
+    drop();
+    if (r != 0) { dfree(own_text); return fail(c, YABPE_E_HIP, "pre-tokeniser failed: %s", hipGetErrorString(hipGetLastError())); }
+    if (po.bad_pos >= 0) {
+        dfree(own_text);
+        *out_bad_pos = po.bad_pos;
+        return fail(c, YABPE_E_UTF8, "invalid UTF-8 at byte %lld", po.bad_pos);
+    }
+    if (own_text) c->pretok_bufs.push_back(own_text);
+    c->pretok_bufs.push_back(po.off);
+    *out_dev_text = d_text;
+    *out_dev_word_off = (uint64_t *)po.off;
+    *out_n_words = po.n_words;
+    return YABPE_OK;
+}
+
+int yabpe_pretokenize_free(yabpe_ctx *c) {
+    if (!c) return YABPE_E_INVALID;
+    for (void *p : c->pretok_bufs) dfree(p);
+    c->pretok_bufs.clear();
     return YABPE_OK;
 }
 

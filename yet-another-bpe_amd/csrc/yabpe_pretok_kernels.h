@@ -1,0 +1,204 @@
+// yabpe_pretok_kernels.h -- the pre-tokeniser on the device (reference trainer.py:136-214).
+//
+// Input: the UTF-8 bytes of the corpus, resident in HBM, cut into chunks (every chunk is a text of its own).
+// Output: u64 word offsets INTO THAT BUFFER (no copy of the text): word i = text[off[i], off[i+1]).  Pre-tokens partition
+// each chunk, so one flag per byte ("a pre-token starts here") describes the result; the flags are compacted into the
+// offsets array by a two-level prefix sum.  All rules live in pretok_logic.h (shared with the CPU model the tests run
+// against regex.findall); the kernels only map bytes to threads.
+//
+// Passes over the text (all streaming, one thread per byte; the per-byte work is a few loads of neighbouring bytes that
+// hit L1/L2):   k_pt_classify  text -> meta (class, continuation, UTF-8 validation: first malformed byte by atomicMin)
+//               k_pt_starts    text, meta -> flags
+//               k_pt_special_* text, meta -> occ -> corrected flags (only when special tokens are configured)
+//               k_pt_count / k_pt_scatter   flags -> offsets
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pretok_logic.h"
+#include "yabpe_aux_kernels.h"
+
+namespace yb {
+
+constexpr int PT_PER_BLOCK = BLOCK * 8; // bytes per workgroup in the count / scatter passes
+
+struct PretokParams {
+    const uint8_t *text;
+    uint8_t *meta;
+    uint8_t *flags;
+    uint8_t *occ;
+    unsigned long long n;
+    const uint8_t *cls;       // class per code point (0x110000 entries)
+    unsigned long long *err;  // smallest malformed byte position (atomicMin), ~0 = none
+    PtSpecials sp;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_pt_mark_chunks(uint8_t *meta, const unsigned long long *chunk_off, uint32_t n_chunks,
+                                                          unsigned long long n) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c < n_chunks && chunk_off[c] < n) meta[chunk_off[c]] = PT_CHUNK0; // (meta was zeroed)
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pt_classify(PretokParams P) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK) {
+        const uint8_t own = P.meta[i] & PT_CHUNK0;
+        unsigned long long end = P.n;
+        for (unsigned long long k = i + 1; k < i + 4 && k < P.n; ++k)
+            if (P.meta[k] & PT_CHUNK0) { // (the only bit of a neighbour's meta byte this pass reads; it never changes)
+                end = k;
+                break;
+            }
+        bool bad = false;
+        const uint8_t m = pt_classify(P.text, i, end, own != 0, P.meta, P.cls, &bad);
+        P.meta[i] = own | m;
+        if (bad) atomicMin(P.err, i);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pt_starts(PretokParams P) {
+    const PtView v{P.text, P.meta, P.n};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK)
+        P.flags[i] = pt_is_start(v, i, -1) ? 1 : 0;
+}
+
+// occurrences of the special tokens; a 256-bit set of their first bytes keeps nearly every thread out of the compare
+__global__ __launch_bounds__(BLOCK) void k_pt_special_find(PretokParams P) {
+    __shared__ uint32_t s_first[8];
+    if (threadIdx.x < 8) s_first[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x < P.sp.n) {
+        const uint32_t o = P.sp.off[threadIdx.x];
+        if (P.sp.off[threadIdx.x + 1] > o) atomicOr(&s_first[P.sp.bytes[o] >> 5], 1u << (P.sp.bytes[o] & 31));
+    }
+    __syncthreads();
+    const PtView v{P.text, P.meta, P.n};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK) {
+        const uint8_t b = P.text[i];
+        uint32_t o = 0;
+        if ((s_first[b >> 5] >> (b & 31)) & 1u) o = pt_special_at(v, P.sp, i);
+        P.occ[i] = (uint8_t)o;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pt_special_resolve(PretokParams P) {
+    const PtView v{P.text, P.meta, P.n};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK)
+        if (P.occ[i] && pt_special_is_head(v, P.sp, P.occ, i)) pt_special_walk(v, P.sp, P.occ, P.flags, i);
+}
+
+// flags -> offsets, pass 1: number of starts per workgroup of PT_PER_BLOCK bytes
+__global__ __launch_bounds__(BLOCK) void k_pt_count(const uint8_t *flags, unsigned long long n, unsigned long long *block_sums) {
+    __shared__ uint32_t s_w[WPB];
+    const unsigned long long base = (unsigned long long)blockIdx.x * PT_PER_BLOCK + (unsigned long long)threadIdx.x * 8;
+    uint32_t cnt = 0;
+    if (base + 8 <= n) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(flags + base); // eight 0/1 bytes
+        cnt = (uint32_t)__popcll(w);
+    } else {
+        for (unsigned long long k = base; k < n; ++k) cnt += flags[k];
+    }
+    cnt = (uint32_t)wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < WPB; ++w) t += s_w[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// pass 2: off[block_base + rank of the start inside the workgroup] = its byte position
+__global__ __launch_bounds__(BLOCK) void k_pt_scatter(const uint8_t *flags, unsigned long long n, const unsigned long long *block_base,
+                                                      unsigned long long *off) {
+    __shared__ uint32_t s_w[WPB];
+    const unsigned long long base = (unsigned long long)blockIdx.x * PT_PER_BLOCK + (unsigned long long)threadIdx.x * 8;
+    uint8_t f[8];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f[k] = base + k < n ? flags[base + k] : 0;
+        cnt += f[k];
+    }
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_sum(cnt);
+    if (lane == 63) s_w[wib] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wib; ++w) woff += s_w[w];
+    unsigned long long idx = block_base[blockIdx.x] + woff + inc - cnt;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (f[k]) off[idx++] = base + k;
+}
+
+struct PretokOut {
+    unsigned long long *off; // n_words + 1
+    unsigned long long n_words;
+    long long bad_pos;       // first malformed UTF-8 byte, -1 if the text is valid
+};
+
+// Runs all passes on `text` (device).  chunk_off: device array of n_chunks chunk starts.  cls: device class table.
+// Scratch (meta, flags, occ) is allocated and released here; out->off is the caller's to free.
+inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n, const unsigned long long *chunk_off, uint32_t n_chunks,
+                       const uint8_t *cls, const PtSpecials &sp_dev, PretokOut *out) {
+    out->off = nullptr;
+    out->n_words = 0;
+    out->bad_pos = -1;
+    if (n == 0) {
+        YB_RET(hipMalloc((void **)&out->off, 8));
+        YB_RET(hipMemsetAsync(out->off, 0, 8, s));
+        YB_RET(hipStreamSynchronize(s));
+        return 0;
+    }
+    uint8_t *meta = nullptr, *flags = nullptr, *occ = nullptr;
+    unsigned long long *err = nullptr, *sums = nullptr, *bases = nullptr;
+    const unsigned long long nb = (n + PT_PER_BLOCK - 1) / PT_PER_BLOCK;
+    int rc = -1;
+    do {
+        if (hipMalloc((void **)&meta, n) != hipSuccess || hipMalloc((void **)&flags, n + 8) != hipSuccess) break;
+        if (hipMalloc((void **)&err, 8) != hipSuccess || hipMalloc((void **)&sums, nb * 8) != hipSuccess) break;
+        if (hipMalloc((void **)&bases, (nb + 1) * 8) != hipSuccess) break;
+        if (sp_dev.n && hipMalloc((void **)&occ, n) != hipSuccess) break;
+        if (hipMemsetAsync(meta, 0, n, s) != hipSuccess || hipMemsetAsync(err, 0xff, 8, s) != hipSuccess) break;
+        const uint32_t grid = (uint32_t)std::min<unsigned long long>((n + BLOCK - 1) / BLOCK, 1u << 20);
+        PretokParams P{text, meta, flags, occ, n, cls, err, sp_dev};
+        hipLaunchKernelGGL(k_pt_mark_chunks, dim3((n_chunks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, meta, chunk_off, n_chunks, n);
+        hipLaunchKernelGGL(k_pt_classify, dim3(grid), dim3(BLOCK), 0, s, P);
+        unsigned long long h_err = 0;
+        if (hipMemcpyAsync(&h_err, err, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+        if (h_err != ~0ull) { // malformed UTF-8: nothing else is computed (the neighbour walks assume valid text)
+            out->bad_pos = (long long)h_err;
+            rc = 0;
+            break;
+        }
+        hipLaunchKernelGGL(k_pt_starts, dim3(grid), dim3(BLOCK), 0, s, P);
+        if (sp_dev.n) {
+            hipLaunchKernelGGL(k_pt_special_find, dim3(grid), dim3(BLOCK), 0, s, P);
+            hipLaunchKernelGGL(k_pt_special_resolve, dim3(grid), dim3(BLOCK), 0, s, P);
+        }
+        hipLaunchKernelGGL(k_pt_count, dim3((uint32_t)nb), dim3(BLOCK), 0, s, flags, n, sums);
+        if (hipGetLastError() != hipSuccess) break;
+        if (exclusive_scan<unsigned long long>(s, sums, nb, bases, nb + 1) != 0) break;
+        unsigned long long total = 0;
+        if (hipMemcpyAsync(&total, bases + nb, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+        if (hipMalloc((void **)&out->off, (total + 1) * 8) != hipSuccess) break;
+        hipLaunchKernelGGL(k_pt_scatter, dim3((uint32_t)nb), dim3(BLOCK), 0, s, flags, n, bases, out->off);
+        if (hipMemcpyAsync(out->off + total, &n, 8, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        out->n_words = total;
+        rc = 0;
+    } while (false);
+    (void)hipFree(meta);
+    (void)hipFree(flags);
+    (void)hipFree(occ);
+    (void)hipFree(err);
+    (void)hipFree(sums);
+    (void)hipFree(bases);
+    if (rc != 0 && out->off) {
+        (void)hipFree(out->off);
+        out->off = nullptr;
+    }
+    return rc;
+}
+
+} // namespace yb

@@ -21,6 +21,17 @@ class YabpeError(RuntimeError):
         self.code = code
 
 
+class Utf8Error(ValueError):
+    """yabpe_pretokenize found malformed UTF-8; .position = UnicodeDecodeError.start inside the buffer."""
+
+    def __init__(self, position: int):
+        super().__init__(f"invalid UTF-8 at byte {position}")
+        self.position = position
+
+
+E_UTF8 = -7
+
+
 class Stats(ctypes.Structure):
     _fields_ = [(n, c_uint64) for n in (
         "n_words", "n_words_input", "n_long_words", "tokens_initial", "tokens_now", "merges_done", "n_tiles",
@@ -40,7 +51,8 @@ SYMBOLS = [
     "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
     "yabpe_iter_log", "yabpe_event_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
-    "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
+    "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_pretokenize", "yabpe_pretokenize_free",
+    "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
 ]
 
 
@@ -73,6 +85,9 @@ def lib() -> ctypes.CDLL:
         L.yabpe_synth_generate.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32, c_int,
                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_free.argtypes = [c_void_p]
+        L.yabpe_pretokenize.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32,
+                                        POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(ctypes.c_int64)]
+        L.yabpe_pretokenize_free.argtypes = [c_void_p]
         L.yabpe_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
         L.yabpe_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
         L.yabpe_comm_unique_id.argtypes = [c_void_p]
@@ -220,6 +235,33 @@ class Context:
 
     def synth_free(self) -> None:
         self._chk(lib().yabpe_synth_free(self._h))
+
+    def pretokenize(self, text, n_bytes: int | None = None, chunk_starts=None, special_tokens=()):
+        """GPT-2 pre-tokenisation on the device (reference trainer.py:136-214).  `text`: bytes / u8 array (staged) or a
+        device address (then n_bytes is required).  chunk_starts: ascending chunk starts, first one 0.
+        -> (dev_text_ptr, dev_word_off_ptr, n_words); raises Utf8Error(position) on malformed UTF-8."""
+        keep = None
+        if isinstance(text, int):
+            ptr, n = c_void_p(text), int(n_bytes)
+        else:
+            keep = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+            ptr, n = c_void_p(keep.ctypes.data if keep.size else 0), int(keep.size)
+        ch = np.ascontiguousarray(chunk_starts if chunk_starts is not None and len(chunk_starts) else [0], dtype=np.uint64)
+        sb = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in special_tokens]
+        spb = np.frombuffer(b"".join(sb) or b"\0", dtype=np.uint8)
+        spo = np.zeros(len(sb) + 1, dtype=np.uint32)
+        if sb:
+            spo[1:] = np.cumsum([len(x) for x in sb])
+        dt, do, nw, bad = c_void_p(), c_void_p(), c_uint64(0), ctypes.c_int64(-1)
+        rc = lib().yabpe_pretokenize(self._h, ptr, n, ch.ctypes.data, len(ch), spb.ctypes.data, spo.ctypes.data, len(sb),
+                                     byref(dt), byref(do), byref(nw), byref(bad))
+        if rc == E_UTF8:
+            raise Utf8Error(bad.value)
+        self._chk(rc)
+        return dt.value or 0, do.value, nw.value
+
+    def pretokenize_free(self) -> None:
+        self._chk(lib().yabpe_pretokenize_free(self._h))
 
     def h2d(self, dev_ptr: int, arr: np.ndarray) -> None:
         arr = np.ascontiguousarray(arr)

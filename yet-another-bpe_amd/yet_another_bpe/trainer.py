@@ -6,7 +6,11 @@ the merge loop itself (:216-302) runs on the GPU through the C ABI in include/ya
 loaded with ctypes by `_native`).  There is no CPU fallback: without the built library and a GPU,
 `_merge_loop` raises.
 
-Host-only steps (file chunking, UTF-8 decode, GPT-2 regex, save format) stay in Python as in the reference.
+Host-only steps (file chunking, save format) stay in Python as in the reference.  Pre-tokenisation (UTF-8 decode +
+GPT-2 regex, trainer.py:136-214) exists twice with identical results: `_preprocess_corpus` runs the `regex` module on
+the host and returns Python lists, as the reference's method does; `train()` on a corpus of 1 MiB or more (or with
+YABPE_PRETOKENIZE=gpu) hands the raw file bytes to `yabpe_pretokenize` instead and never builds Python objects per
+pre-token (YABPE_PRETOKENIZE=host forces the host path).
 """
 from __future__ import annotations
 
@@ -80,6 +84,9 @@ class BBPETrainer:
         if not files:
             raise ValueError("At least one file must be provided")
         paths = [Path(f) if isinstance(f, str) else f for f in files]
+        mode = os.environ.get("YABPE_PRETOKENIZE", "auto")
+        if mode == "gpu" or (mode == "auto" and sum(p.stat().st_size for p in paths if p.exists()) >= (1 << 20)):
+            return self._train_device(paths)
         pretokens = self._pretokenize(paths)
         specials = list(self.config.special_tokens)
         if not pretokens:  # empty corpus: base vocab only (trainer.py:81-85)
@@ -98,6 +105,62 @@ class BBPETrainer:
         self._vocab = vocab
         self._merges = merges
         return BBPEModel(vocab=vocab, merges=merges, special_tokens=specials)
+
+    def _train_device(self, paths: Sequence[Path]) -> BBPEModel:
+        """train() with the pre-tokeniser on the GPU: file bytes -> yabpe_pretokenize -> word offsets in HBM ->
+        yabpe_load_words (equal pre-tokens pooled on the device) -> merge loop.  Same results as the host path."""
+        from . import _native  # fails loudly when libyabpe.so / a GPU is missing
+
+        specials = list(self.config.special_tokens)
+        pieces: list[np.ndarray] = []
+        chunks: list[tuple[int, Path, int]] = []  # (start in the joined buffer, file, start in the file)
+        total = 0
+        for path in paths:
+            if not path.exists():
+                raise FileNotFoundError(f"File not found: {path}")
+            ranges = self._chunk_ranges(path)
+            if not ranges:
+                continue
+            data = np.fromfile(path, dtype=np.uint8)
+            for start, stop in ranges:  # (the reference can skip bytes between chunks, trainer.py:196-197)
+                chunks.append((total, path, start))
+                pieces.append(data[start:stop])
+                total += stop - start
+        base = self._base_tokens()
+        num_merges = max(0, self.config.vocab_size - len(base))
+        empty = BBPEModel(vocab={t: i for i, t in enumerate(base)}, merges=[], special_tokens=specials)
+        if total == 0:
+            self._vocab, self._merges = dict(empty.vocab), []
+            return empty
+        text = pieces[0] if len(pieces) == 1 else np.concatenate(pieces)
+        with _native.Context() as ctx:
+            try:
+                dev_text, dev_off, n_words = ctx.pretokenize(text, chunk_starts=[c[0] for c in chunks], special_tokens=specials)
+            except _native.Utf8Error as e:
+                k = max(i for i, c in enumerate(chunks) if c[0] <= e.position)
+                g0, path, f0 = chunks[k]
+                raise ValueError(f"File {path} contains invalid UTF-8 at position {f0 + e.position - g0}.") from e
+            if n_words == 0 or num_merges == 0:
+                self._vocab, self._merges = dict(empty.vocab), []
+                return empty
+            ctx.set_vocab(base)
+            ctx.load_words_ptr(dev_text, dev_off, n_words, dedup=os.environ.get("YABPE_LAYOUT", "dedup") != "flat")
+            left, right, merged, _count = ctx.train(num_merges, int(self.config.min_frequency))
+            self.last_stats = ctx.stats()
+        vocab, merges = self._decode_merges(base, left, right, merged)
+        self._vocab = vocab
+        self._merges = merges
+        return BBPEModel(vocab=vocab, merges=merges, special_tokens=specials)
+
+    @staticmethod
+    def _decode_merges(base: Sequence[bytes], left, right, merged):
+        toks = list(base)
+        merges: list[tuple[bytes, bytes]] = []
+        for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+            merges.append((toks[l], toks[r]))
+            if m == len(toks):  # a fresh id; otherwise the bytes already existed (trainer.py:298-300)
+                toks.append(toks[l] + toks[r])
+        return {t: i for i, t in enumerate(toks)}, merges
 
     def save(self, output_dir: str | Path) -> None:
         """vocab.json / merges.txt / special_tokens.json in the reference's format (trainer.py:94-117)."""
@@ -210,10 +273,4 @@ class BBPETrainer:
             ctx.load_words(flat, off, freq)
             left, right, merged, _count = ctx.train(num_merges, int(self.config.min_frequency))
             self.last_stats = ctx.stats()
-        toks = list(base)
-        merges: list[tuple[bytes, bytes]] = []
-        for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
-            merges.append((toks[l], toks[r]))
-            if m == len(toks):  # a fresh id; otherwise the bytes already existed (trainer.py:298-300)
-                toks.append(toks[l] + toks[r])
-        return {t: i for i, t in enumerate(toks)}, merges
+        return self._decode_merges(base, left, right, merged)
