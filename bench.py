@@ -67,6 +67,7 @@ def main() -> None:
     ap.add_argument("--roofline-merges", type=int, default=2500, help="merges of the auxiliary full-scan pass (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup-line", action="store_true")
+    ap.add_argument("--no-pretok-line", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +227,23 @@ def main() -> None:
         out["dedup_layout"] = {"merges_per_sec": round(rd["n_merges"] / dt, 2), "seconds": round(dt, 3),
                                "unique_words": rd["stats"]["n_words"], "same_merges_as_flat": same,
                                "device_ms": {"dedup_load_count": round(rd["stats"]["load_ms"], 2), "merge_loop": round(rd["stats"]["train_ms"], 2)}}
+    if rank == 0 and not args.no_pretok_line and world == 1:
+        # the step before the path: GPT-2 pre-tokenisation of text resident in HBM.  Text = the config-2
+        # style generator at this run's size (space + lower-case word, Zipf over 50k types), pre-tokens must equal its words.
+        with _native.Context(local_rank) as pt:
+            tb, _to, tw, tn = pt.synth_generate(args.target_mib << 20, 50_000, 2, b"abcdefghijklmnopqrstuvwxyz", True)
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _dt, _do, nw_pt = pt.pretokenize(tb, n_bytes=tn, special_tokens=["<|endoftext|>"])
+                dt = time.perf_counter() - t1
+                pt.pretokenize_free()
+                best = dt if best is None else min(best, dt)
+            out["pretokenize"] = {"GB_per_sec": round(tn / best / 1e9, 2), "ms": round(best * 1e3, 2), "text_bytes": tn, "pretokens": nw_pt,
+                                  "equals_generator_words": bool(nw_pt == tw),
+                                  "note": "yabpe_pretokenize (UTF-8 validation + GPT-2 split + special tokens -> word offsets in HBM), "
+                                          "wall time incl. scratch allocation, best of 3; not part of `value`"}
     if rank == 0 and not args.no_cpu_baseline:
         cb, (cflat, coff, cmg) = cpu_baseline(gen, pb, po, n_words, n_bytes, args.merges, args.cpu_sample_mib << 20, specials)
         out["cpu_baseline"] = cb

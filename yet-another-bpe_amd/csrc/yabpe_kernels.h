@@ -318,14 +318,36 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
 
 template <class V>
 __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st) {
-    for (int i = threadIdx.x; i < AGG_N; i += BLOCK) {
-        uint32_t k = g.keys[i];
-        long long v = (long long)g.vals[i];
-#ifndef YB_DBG_NOFLUSH
-        if (k != EMPTY && v != 0) gt_add(t, st, k, v);
-#else
-        if (k == 12345u && v == 77) gt_add(t, st, k, v);
+    // every thread owns AGG_N / BLOCK entries; the table keys at their home slots are requested together, so that the
+    // usual case (the key sits at its home slot) costs one round trip for all of them
+    constexpr int PER = AGG_N / BLOCK;
+    uint32_t k[PER], home[PER], tk[PER];
+    long long v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = threadIdx.x + q * BLOCK;
+        k[q] = g.keys[i];
+        v[q] = (long long)g.vals[i];
+#ifdef YB_DBG_NOFLUSH
+        if (!(k[q] == 12345u && v[q] == 77)) v[q] = 0;
 #endif
+        if (k[q] == EMPTY) v[q] = 0;
+        home[q] = 0;
+        tk[q] = EMPTY;
+        if (v[q] != 0) {
+            home[q] = pt_home(t, k[q]);
+            tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (v[q] == 0) continue;
+        if (tk[q] == k[q]) {
+            atomicAdd(&t.cnt[home[q]], (unsigned long long)v[q]);
+            if (v[q] > 0 && t.touched) atomicOr(&t.touched[home[q] >> 5], 1u << (home[q] & 31));
+        } else {
+            gt_add(t, st, k[q], v[q]);
+        }
     }
 }
 
@@ -1236,7 +1258,9 @@ struct ScanSkipParams {
 // INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
 // (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
 // FULL (sparse merges): the rest is rewritten here too (slow_tile) -- the few tiles involved do not need k_slow's
-// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.
+// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.  In this form
+// matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
+// already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
 template <bool INLINE, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
@@ -1340,7 +1364,25 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
             // A rewrite stores to HBM, and on gfx950 stores queue in the same in-order vmcnt as this wave's prefetched
             // loads: rewriting here would stall the scan behind every store.  Matched tiles are only noted; they are
             // rewritten after the candidate loop, when no load of this wave is waiting behind the stores.
-            if (do_inline) {
+            if (FULL) {
+                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
+                const unsigned long long holders = __ballot(mine != 0);
+                const int lane_s = __ffsll((long long)holders) - 1;
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
+                bool handled = false;
+                if constexpr (INLINE) {
+                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
+                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        handled = true;
+                    }
+                }
+                if (handled) {
+                } else if constexpr (FULL) {
+                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
+                } else if (lane == 0) {
+                    my_work[atomicAdd(&s_hits, 1u)] = cur;
+                }
+            } else if (do_inline) {
                 if (lane == 0) s_rew[atomicAdd(&s_nrew, 1u)] = cur;
             } else {
                 if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
@@ -1348,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         }
         __syncthreads();
         YB_SCAN_STAMP(2);
-        if (do_inline) {
+        if (!FULL && do_inline) {
             const uint32_t nr = s_nrew;
             uint32_t k = wib;
             uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
