@@ -148,7 +148,7 @@ struct yabpe_ctx {
     bool split_mode = false;
     std::vector<float> ev_scan_us;
     // skip index
-    uint32_t *sig = nullptr;
+    unsigned long long *sig = nullptr;
     uint32_t sig_stride = 0;
     unsigned long long *blk_read = nullptr;  // [MAX_LISTS] tiles read by k_scan_skip, accumulated
     uint64_t scan_skip_launches = 0;
@@ -611,7 +611,7 @@ int build_signatures(yabpe_ctx *c) {
         dfree(c->sig);
         c->sig = nullptr;
         c->sig_stride = (uint32_t)((c->n_tiles + 31u) & ~31u);  // rows start 128-B aligned
-        TRY(dmalloc(c, &c->sig, (uint64_t)SIG_WORDS * c->sig_stride));
+        TRY(dmalloc(c, &c->sig, (uint64_t)SIG_ROWS * c->sig_stride));
     }
     SigParams P{c->tiles, c->tile_len, c->n_tiles, c->sig, c->sig_stride};
     const uint32_t n_groups = (uint32_t)((c->n_tiles + SIG_TILES - 1) / SIG_TILES);

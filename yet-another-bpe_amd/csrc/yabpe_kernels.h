@@ -32,11 +32,9 @@ constexpr int AGG_N = 1024;          // LDS delta-aggregator entries per workgro
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PADPAD = (YB_PAD << 16) | YB_PAD;
 constexpr int LONG_CH = 4096;        // long-word path: tokens per LDS chunk
-constexpr int SIG_K = 3;             // tile signature: a Bloom filter of the adjacent pairs present in the tile, SIG_K hash
-constexpr int SIG_PART_LOG2 = 13;    // functions, each with its own partition of 8,192 bits (a tile holds <= 1023 pairs)
-constexpr int SIG_PART_WORDS = 1 << (SIG_PART_LOG2 - 5);
-constexpr int SIG_WORDS = SIG_K * SIG_PART_WORDS;
-constexpr int SIG_TILES = 16;        // k_build_sig: tiles whose signatures one workgroup transposes together (64-B rows)
+constexpr int SIG_ROWS = 512;        // tile signature: a blocked Bloom filter of the adjacent pairs present in the tile --
+constexpr int SIG_ROWS_LOG2 = 9;     // 512 blocks of 64 bits (4 KiB per tile); a pair owns 3 bits inside ONE block
+constexpr int SIG_TILES = 8;         // k_build_sig: tiles whose signatures one workgroup transposes together (64-B rows)
 constexpr int MAX_LISTS_PROF = 4096;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time (x kt)
 constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
@@ -131,14 +129,16 @@ __device__ __forceinline__ uint32_t hash32(uint32_t k) {
     return k;
 }
 
-// Tile signatures (skip index).  sig[w * stride + tile], w < SIG_WORDS: transposed, so that the threads of a workgroup
-// that test 256 consecutive tiles read consecutive words.  Partition k (rows [k * SIG_PART_WORDS, (k+1) * SIG_PART_WORDS))
-// holds bit h_k(pair) for every adjacent pair of the tile.  A signature is a SUPERSET of what the tile holds: bits are
-// added when a rewrite creates a pair and only a rebuild (k_build_sig) clears stale ones.  With ~1,000 pairs per tile the
-// partitions are ~11 % full, so a tile without the pair passes all three tests with probability ~0.1 %.
+// Tile signatures (skip index).  sig[row * stride + tile], row < SIG_ROWS, one u64 per (row, tile): transposed, so that
+// the threads of a workgroup that test consecutive tiles read consecutive words.  A pair hashes to one row and to 3 bit
+// positions inside that 64-bit block ("blocked" Bloom filter): the test reads ONE word per tile, and a rewrite that
+// creates a pair sets its bits with ONE atomic -- with three separate partitions it took three, on three different cache
+// lines, and those scattered read-modify-writes were 9 % of the whole run.  A signature is a SUPERSET of what the tile
+// holds: bits are added when a rewrite creates a pair and only a rebuild (k_build_sig) clears stale ones.  With ~1,000
+// pairs per tile a block holds ~2 pairs (~9 % of its bits); a tile without the pair passes with probability ~0.15 %.
 struct SigHash {
-    uint32_t row[SIG_K]; // word row inside the signature
-    uint32_t bit[SIG_K]; // bit inside that word
+    uint32_t row;
+    unsigned long long mask;
 };
 __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
     x ^= x >> 16;
@@ -150,39 +150,24 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 }
 __device__ __forceinline__ SigHash sig_hash(uint32_t key) { // key = left << 16 | right
     const uint32_t x = fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
-    const uint32_t y = fmix32(key ^ 0x5BD1E995u);
-    const uint32_t h0 = x >> (32 - SIG_PART_LOG2), h1 = x & ((1u << SIG_PART_LOG2) - 1u), h2 = y >> (32 - SIG_PART_LOG2);
     SigHash H;
-    H.row[0] = h0 >> 5;
-    H.row[1] = SIG_PART_WORDS + (h1 >> 5);
-    H.row[2] = 2 * SIG_PART_WORDS + (h2 >> 5);
-    H.bit[0] = h0 & 31;
-    H.bit[1] = h1 & 31;
-    H.bit[2] = h2 & 31;
+    H.row = x >> (32 - SIG_ROWS_LOG2);
+    H.mask = (1ull << (x & 63u)) | (1ull << ((x >> 6) & 63u)) | (1ull << ((x >> 12) & 63u));
     return H;
 }
-__device__ __forceinline__ void sig_set_pair(uint32_t *sig, uint32_t stride, uint32_t tile, uint32_t key) {
+__device__ __forceinline__ void sig_set_pair(unsigned long long *sig, uint32_t stride, uint32_t tile, uint32_t key) {
     const SigHash H = sig_hash(key);
-#pragma unroll
-    for (int k = 0; k < SIG_K; ++k) atomicOr(&sig[(size_t)H.row[k] * stride + tile], 1u << H.bit[k]);
+    atomicOr(&sig[(size_t)H.row * stride + tile], H.mask);
 }
-// The three words a scan tests for one tile, as row pointers (the pair is fixed for the whole launch).
+// The word a scan tests for one tile, as a row pointer (the pair is fixed for the whole launch).
 struct SigProbe {
-    const uint32_t *p[SIG_K];
-    uint32_t bit[SIG_K];
-    __device__ __forceinline__ bool maybe(uint32_t tile) const {
-        return ((p[0][tile] >> bit[0]) & (p[1][tile] >> bit[1]) & (p[2][tile] >> bit[2]) & 1u) != 0;
-    }
+    const unsigned long long *p;
+    unsigned long long mask;
+    __device__ __forceinline__ bool maybe(uint32_t tile) const { return (p[tile] & mask) == mask; }
 };
-__device__ __forceinline__ SigProbe sig_probe(const uint32_t *sig, uint32_t stride, uint32_t key) {
+__device__ __forceinline__ SigProbe sig_probe(const unsigned long long *sig, uint32_t stride, uint32_t key) {
     const SigHash H = sig_hash(key);
-    SigProbe Q;
-#pragma unroll
-    for (int k = 0; k < SIG_K; ++k) {
-        Q.p[k] = sig + (size_t)H.row[k] * stride;
-        Q.bit[k] = H.bit[k];
-    }
-    return Q;
+    return SigProbe{sig + (size_t)H.row * stride, H.mask};
 }
 
 // Within one wave LDS operations complete in order; this keeps the compiler from moving a lane's LDS reads
@@ -490,7 +475,7 @@ struct ApplyParams {
     PairTable out; // where deltas go: the pair table (1 GPU) or the per-rank delta table (multi-GPU)
     DevState *st;
     unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
-    uint32_t *sig;                 // tile signatures (may be NULL)
+    unsigned long long *sig;       // tile signatures (may be NULL)
     uint32_t sig_stride;
 };
 
@@ -709,16 +694,13 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
     }
     YB_SS_STAMP(2);
-    // the two pairs this site creates are now present in the tile: 2 x SIG_K signature bits, one per lane
-    if (P.sig && !dead && lane < 2 * SIG_K) {
-        const bool second = lane >= SIG_K;
-        if (second ? right : left) {
-            const SigHash H = sig_hash(second ? yb_pairkey(c, R) : yb_pairkey(L, c));
-            const int k = lane - (second ? SIG_K : 0);
-            const uint32_t row = k == 0 ? H.row[0] : k == 1 ? H.row[1] : H.row[2];
-            const uint32_t bit = k == 0 ? H.bit[0] : k == 1 ? H.bit[1] : H.bit[2];
-            atomicOr(&P.sig[(size_t)row * P.sig_stride + tile], 1u << bit);
-        }
+    // the two pairs this site creates are now present in the tile: one signature word each, set by lanes 0 and 1
+#ifdef YB_DBG_NOSIGSET
+    if (false) {
+#else
+    if (P.sig && !dead && lane < 2) {
+#endif
+        if (lane ? right : left) sig_set_pair(P.sig, P.sig_stride, tile, lane ? yb_pairkey(c, R) : yb_pairkey(L, c));
     }
     YB_SS_STAMP(3);
 
@@ -1183,24 +1165,24 @@ struct SigParams {
     const uint16_t *tiles;
     const uint32_t *tile_len;
     uint32_t n_tiles;
-    uint32_t *sig;
+    unsigned long long *sig;
     uint32_t sig_stride;
 };
 __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
-    constexpr int ROW = SIG_WORDS + 4; // +4: the transposed read below walks the tiles with a stride of 4 banks
-    __shared__ uint32_t s_sig[SIG_TILES][ROW];
+    constexpr int ROW = SIG_ROWS + 2; // (padding: the transposed read below walks the tiles)
+    __shared__ unsigned long long s_sig[SIG_TILES][ROW];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_groups = (P.n_tiles + SIG_TILES - 1) / SIG_TILES;
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const uint32_t base = grp * SIG_TILES;
-        for (int w = threadIdx.x; w < SIG_TILES * ROW; w += BLOCK) (&s_sig[0][0])[w] = 0u;
+        for (int w = threadIdx.x; w < SIG_TILES * ROW; w += BLOCK) (&s_sig[0][0])[w] = 0ull;
         __syncthreads();
         for (int k = wib; k < SIG_TILES; k += WPB) {
             const uint32_t tile = base + k;
             const uint32_t len = tile < P.n_tiles ? P.tile_len[tile] : 0u;
             if (!len) continue;
-            uint32_t *sg = s_sig[k];
+            unsigned long long *sg = s_sig[k];
             const TileRegs r = load_tile(P.tiles, tile, len, lane);
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
@@ -1216,15 +1198,14 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
                     const uint32_t y = j < 7 ? elem16(v, j + 1) : nx;
                     if (p0 + j < len && x < YB_PAD && y < YB_PAD) {
                         const SigHash H = sig_hash(yb_pairkey(x, y));
-#pragma unroll
-                        for (int q = 0; q < SIG_K; ++q) atomicOr(&sg[H.row[q]], 1u << H.bit[q]);
+                        atomicOr(&sg[H.row], H.mask);
                     }
                 }
             }
         }
         __syncthreads();
-        // transposed store: 16 consecutive tiles of one row are 64 contiguous bytes
-        for (int idx = threadIdx.x; idx < SIG_WORDS * SIG_TILES; idx += BLOCK) {
+        // transposed store: 8 consecutive tiles of one row are 64 contiguous bytes
+        for (int idx = threadIdx.x; idx < SIG_ROWS * SIG_TILES; idx += BLOCK) {
             const int row = idx / SIG_TILES, col = idx % SIG_TILES;
             if (base + col < P.n_tiles) P.sig[(size_t)row * P.sig_stride + base + col] = s_sig[col][row];
         }
@@ -1262,7 +1243,7 @@ struct ScanSkipParams {
 // matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
 // already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
 template <bool INLINE, bool FULL, bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
+__global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 4 workgroups per CU)
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     constexpr bool REWRITES = INLINE || FULL;
     static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
@@ -1337,25 +1318,33 @@ __global__ __launch_bounds__(BLOCK) void k_scan_skip(ScanSkipParams Q) {
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
-        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched
+        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched (two in the
+        // FULL form: its rewrite code needs the registers, and a wave rarely has more than three candidates there)
+        constexpr bool DEEP = !FULL;
         uint32_t j = wib;
         uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
         uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
-        uint2 it2 = j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
+        uint2 it2 = DEEP && j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
         TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
         TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
-        TileRegs q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+        TileRegs q2 = q1;
+        if constexpr (DEEP) q2 = load_tile(P.tiles, it2.x, it2.y, lane);
         while (j < n) {
             const uint2 cur = it0;
             const TileRegs r = q0;
             it0 = it1;
             q0 = q1;
-            it1 = it2;
-            q1 = q2;
             j += WPB;
-            if (j + 2 * WPB < n) {
-                it2 = s_list[j + 2 * WPB];
-                q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+            if constexpr (DEEP) {
+                it1 = it2;
+                q1 = q2;
+                if (j + 2 * WPB < n) {
+                    it2 = s_list[j + 2 * WPB];
+                    q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+                }
+            } else if (j + WPB < n) {
+                it1 = s_list[j + WPB];
+                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
             }
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
