@@ -180,7 +180,7 @@ def main() -> None:
             "full_stream_equivalent_GBps": round(st["scan_algo_bytes_sampled"] / secs / 1e9, 1) if n_l else None,
             "avg_fraction_of_tiles_read": round(tiles_read / max(1, st["n_tiles"]), 4),
             "apply_phase_avg_us": round(1e3 * st["apply_ms_sampled"] / st["apply_launches_sampled"], 2),
-            "note": "k_scan_skip tests a 16-B signature per tile and reads only tiles that may hold the pair; "
+            "note": "k_scan_skip tests 12 B per tile (length + one 64-bit signature word) and reads only tiles that may hold the pair; "
                     "full_stream_equivalent = sum 2*(T_i+W) / time, i.e. what a full scan would have had to sustain",
         }
     aux_merges = min(args.merges, args.roofline_merges)

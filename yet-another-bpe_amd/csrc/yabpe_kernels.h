@@ -181,14 +181,16 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // ---------------------------------------------------------------- global pair table
-__device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d) {
+// `inserted`: optional per-thread counter of new keys; the caller then adds its wave's total to *t.entries itself (one
+// atomic per wave on that one hot address instead of one per new key).
+__device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
     uint32_t s = pt_home(t, key);
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
         uint32_t k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == EMPTY) {
             k = atomicCAS(&t.keys[s], EMPTY, key);
             if (k == EMPTY) {
-                atomicAdd(t.entries, 1ull);
+                if (inserted) ++*inserted; else atomicAdd(t.entries, 1ull);
                 k = key;
             }
         }
@@ -324,6 +326,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    uint32_t ins = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         if (v[q] == 0) continue;
@@ -331,9 +334,14 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             atomicAdd(&t.cnt[home[q]], (unsigned long long)v[q]);
             if (v[q] > 0 && t.touched) atomicOr(&t.touched[home[q] >> 5], 1u << (home[q] & 31));
         } else {
-            gt_add(t, st, k[q], v[q]);
+            gt_add(t, st, k[q], v[q], &ins);
         }
     }
+    // new keys of this wave (ins <= PER per thread): three ballots give the total
+    uint32_t total = 0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) total += (uint32_t)__popcll(__ballot((ins >> b) & 1u)) << b;
+    if (total && (threadIdx.x & 63) == 0) atomicAdd(t.entries, (unsigned long long)total);
 }
 
 // ---------------------------------------------------------------- tile access helpers
@@ -1262,11 +1270,13 @@ __global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParam
         YB_SCAN_STAMP(7);
         return;
     }
-    if (st->done | st->halt) return;
+    // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
+    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c;
+    if (st_stop) return;
     const uint32_t n_blocks = Q.scan_blocks;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st_a, st_b, st_c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     const uint32_t a = C.a, b = C.b;
     const uint32_t mk = yb_memkey(a, b);
@@ -2236,11 +2246,11 @@ struct CandParams {
     SelectParams sel;
 };
 
+// (count and key are requested together: this kernel is a chain of dependent round trips, not a bandwidth problem)
 __device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best &best) {
     const long long cn = (long long)P.table.cnt[s];
-    if (cn <= 0 || (unsigned long long)cn < best.cnt) return;
     const uint32_t k = P.table.keys[s];
-    if (k == EMPTY) return;
+    if (cn <= 0 || (unsigned long long)cn < best.cnt || k == EMPTY) return;
     Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
     if (best_gt(e, best)) best = e;
 }
@@ -2252,10 +2262,11 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     if (blockIdx.x == 0) YB_SEL_STAMP(0);
     if (blockIdx.x == 0) YB_SEL_STAMP(8);
 #endif
-    if (!(P.st->done | P.st->halt)) {
+    const uint32_t stop = P.st->done | P.st->halt; // (these three loads do not depend on each other: one round trip)
+    const unsigned long long T = P.cs->T;
+    const uint32_t n0 = min(P.cs->n, CAND_CAP);
+    if (!stop) {
         Best best{0ull, 0u, EMPTY, 0u, 0u};
-        const unsigned long long T = P.cs->T;
-        const uint32_t n0 = min(P.cs->n, CAND_CAP);
         const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
         for (uint32_t i = tid; i < n0; i += nth) cand_eval(P, P.cand[i], best);
         const uint32_t words = (P.table.cap + 31) >> 5;
