@@ -191,3 +191,14 @@ def gpu_sharded(rank, world, dist, scenario):
         if m == len(toks):
             toks.append(toks[l] + toks[r])
     return out, int(stats["n_words"]), int(stats["table_rebuilds"]), int(stats["retiles"])
+
+
+def gpu_text_sharded(rank, world, dist, path, chunk_size, vocab_size, specials):
+    """Text in, merges out: each rank pre-tokenises its chunks of the file on the (shared) GPU."""
+    from yet_another_bpe import _native
+    from yet_another_bpe.distributed import train_text_sharded
+    from yet_another_bpe.trainer import BBPETrainerConfig
+
+    cfg = BBPETrainerConfig(vocab_size=vocab_size, min_frequency=1, special_tokens=specials, chunk_size_bytes=chunk_size)
+    model = train_text_sharded(lambda: _native.Context(0), [path], cfg, rank, world, transport="torch", options={"verify": 1})
+    return [(a.hex(), b.hex()) for a, b in model.merges], len(model.vocab)

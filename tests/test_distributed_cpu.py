@@ -45,3 +45,18 @@ def test_sharded_protocol_equals_single_rank(world):
     for merges, vocab_len in outs:
         assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp_merges
         assert vocab_len == len(exp_vocab)
+
+
+def test_plan_chunk_shards_partitions_and_balances():
+    from yet_another_bpe.distributed import plan_chunk_shards
+
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 2, 7, 50):
+            sizes = rng.integers(1, 1000, size=n).tolist()
+            plan = plan_chunk_shards(sizes, world)
+            assert len(plan) == world and plan[0][0] == 0 and plan[-1][1] == n
+            assert all(a <= b for a, b in plan) and all(plan[i][1] == plan[i + 1][0] for i in range(world - 1))
+            if n >= 4 * world:
+                loads = [sum(sizes[a:b]) for a, b in plan]
+                assert max(loads) - min(loads) <= 2 * max(sizes)

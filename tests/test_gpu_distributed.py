@@ -61,3 +61,21 @@ def test_rccl_transport_single_rank_smoke():
         if m == len(toks):
             toks.append(toks[l] + toks[r])
     assert got == exp
+
+
+def test_text_in_model_out_two_ranks(golden_dir, monkeypatch, tmp_path):
+    """BASELINE configs[4] shape on one GPU: every rank pre-tokenises its chunks of the text on the device, pools its
+    pre-tokens and joins the collective merge loop; result = the single-process trainer with the same chunk size."""
+    from yet_another_bpe.trainer import BBPETrainer, BBPETrainerConfig
+
+    monkeypatch.setenv("YABPE_PRETOKENIZE", "host")
+    for chunk in (16384, 1 << 30):  # 9 chunks over 2 ranks / one chunk: the second rank holds no words at all
+        cfg = BBPETrainerConfig(vocab_size=700, min_frequency=1, special_tokens=SP, chunk_size_bytes=chunk)
+        exp = BBPETrainer(cfg).train([golden_dir / "corpus.en"])
+        outs = dist_workers.spawn(dist_workers.gpu_text_sharded, 2, str(golden_dir / "corpus.en"), chunk, 700, SP, timeout=900)
+        for merges, nv in outs:
+            assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp.merges and nv == len(exp.vocab)
+    bad = tmp_path / "bad.txt"
+    bad.write_bytes(b"good " * 5000 + b"\xff" + b" more" * 5000)
+    with pytest.raises(AssertionError, match="contains invalid UTF-8 at position 25000"):
+        dist_workers.spawn(dist_workers.gpu_text_sharded, 2, str(bad), 8192, 300, SP, timeout=300)

@@ -886,7 +886,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         total_bytes = dd.total_bytes;
         off_base = 0;
     }
-    c->weighted = d_freq != nullptr;
+    // (a rank that holds no words must still run the layout its peers run: the collectives differ between the layouts)
+    c->weighted = d_freq != nullptr || (flags & YABPE_LOAD_DEDUP) != 0;
     c->n_words = n_words;
     c->tokens_initial = total_bytes;
 

@@ -124,6 +124,75 @@ def train_sharded(ctx_factory, flat: np.ndarray, off: np.ndarray, freq, base_tok
         return left, right, merged, count, ctx.stats()
 
 
+def plan_chunk_shards(sizes: Sequence[int], world: int) -> list[tuple[int, int]]:
+    """Contiguous chunk ranges [c0, c1) per rank, balanced by bytes (chunks are the units the pre-tokeniser treats as
+    separate texts, reference trainer.py:172-198, so any assignment of whole chunks gives the same pre-tokens)."""
+    cum = np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.int64))])
+    total = int(cum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(max(bounds[-1], int(np.searchsorted(cum, (total * r) // world, side="left"))))
+    bounds.append(len(sizes))
+    return [(min(bounds[r], len(sizes)), min(bounds[r + 1], len(sizes))) for r in range(world)]
+
+
+def train_text_sharded(ctx_factory, files, config, rank: int, world: int, transport: str = "rccl", options: dict | None = None):
+    """BBPETrainer.train() over several GPUs, text in, model out (BASELINE configs[4] shape): every rank reads ITS chunks
+    of the files, pre-tokenises them on its GPU (yabpe_pretokenize), pools equal pre-tokens locally and joins the
+    collective merge loop.  Chunk cuts are the reference's (config.chunk_size_bytes), so the result equals the
+    single-process train() with the same config.  Returns a BBPEModel (the same on every rank)."""
+    from pathlib import Path
+
+    from . import _native
+    from .trainer import BBPEModel, BBPETrainer
+
+    tr = BBPETrainer(config)
+    paths = [Path(f) for f in files]
+    for p in paths:
+        if not p.exists():
+            raise FileNotFoundError(f"File not found: {p}")
+    chunks = [(p, a, b) for p in paths for a, b in tr._chunk_ranges(p)]
+    c0, c1 = plan_chunk_shards([b - a for _, a, b in chunks], world)[rank] if chunks else (0, 0)
+    pieces, starts, total = [], [], 0
+    for p, a, b in chunks[c0:c1]:
+        starts.append(total)
+        pieces.append(np.fromfile(p, dtype=np.uint8, count=b - a, offset=a))
+        total += b - a
+    base = tr._base_tokens()
+    specials = list(config.special_tokens)
+    num_merges = max(0, config.vocab_size - len(base))
+    with ctx_factory() as ctx:
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_vocab(base)
+        attach(ctx, rank, world, transport)
+        err = None
+        n_words = 0
+        if total:
+            text = pieces[0] if len(pieces) == 1 else np.concatenate(pieces)
+            try:
+                dev_text, dev_off, n_words = ctx.pretokenize(text, chunk_starts=starts, special_tokens=specials)
+            except _native.Utf8Error as e:
+                k = max(i for i, s0 in enumerate(starts) if s0 <= e.position)
+                p, a, _ = chunks[c0 + k]
+                err = (c0 + k, f"File {p} contains invalid UTF-8 at position {a + e.position - starts[k]}.")
+        if world > 1:  # every rank must learn about a bad chunk anywhere, or the others would wait in the merge loop
+            import torch.distributed as dist
+
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            err = min((e for e in errs if e), default=None)
+        if err:
+            raise ValueError(err[1])
+        if n_words:
+            ctx.load_words_ptr(dev_text, dev_off, n_words, dedup=True)
+        else:
+            ctx.load_words(np.zeros(0, np.uint8), np.zeros(1, np.uint64), None, dedup=True)  # no words here: same layout as the peers
+        left, right, merged, _count = ctx.train(num_merges, int(config.min_frequency))
+    vocab, merges = BBPETrainer._decode_merges(base, left, right, merged)
+    return BBPEModel(vocab=vocab, merges=merges, special_tokens=specials)
+
+
 class ShardedRunner:
     """bench.py helper: the corpus is already on every rank's GPU; each rank trains on its word range."""
 
