@@ -37,12 +37,13 @@ extern "C" int pretok_model(const uint8_t *text, uint64_t n, const uint64_t *chu
                 break;
             }
         bool bad = false;
-        const uint8_t m = pt_classify(text, i, end, (meta[i] & PT_CHUNK0) != 0, meta.data(), g_cls.data(), &bad);
+        const PtView v0{text, meta.data(), n, 0};
+        const uint8_t m = pt_classify(v0, i, end, g_cls.data(), &bad);
         meta[i] = (uint8_t)((meta[i] & PT_CHUNK0) | m);
         if (bad && *err_pos < 0) *err_pos = (int64_t)i;
     }
     if (*err_pos >= 0) return 0;
-    PtView v{text, meta.data(), n};
+    PtView v{text, meta.data(), n, 0};
     for (uint64_t i = 0; i < n; ++i) flags_out[i] = pt_is_start(v, i, -1) ? 1 : 0;
     if (n_sp) {
         uint32_t max_len = 0;

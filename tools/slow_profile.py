@@ -12,10 +12,12 @@ with _native.Context() as g:
     pb, po, nw, nb = g.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
     with _native.Context() as ctx:
         ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw)
-        ctx.train(1000, 1)
+        m0, m1 = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1000, 4000)  # merges [m0, m1) are profiled
         out = (ctypes.c_uint64 * 8)()
+        if m0:
+            ctx.train(m0, 1)
         _native.lib().yabpe_debug_slow_profile(out); a = list(out)
-        ctx.train(3000, 1)
+        ctx.train(m1 - m0, 1)
         _native.lib().yabpe_debug_slow_profile(out); b = list(out)
 d = [y - x for x, y in zip(a, b)]
 print("tiles", d[0])

@@ -41,9 +41,12 @@ enum : uint8_t {
 };
 
 struct PtView {
-    const uint8_t *text;
-    const uint8_t *meta; // per byte: class | PT_CONT | PT_CHUNK0
-    uint64_t n;
+    const uint8_t *text; // text[j - org] = byte j of the corpus (org = 0: the arrays are the whole corpus; the fused kernel
+    const uint8_t *meta; // works on a window staged in LDS and sets org to the window's first position)
+    uint64_t n;          // length of the corpus (positions >= n do not exist)
+    uint64_t org;
+    YB_HD uint8_t T(uint64_t j) const { return text[j - org]; }
+    YB_HD uint8_t M(uint64_t j) const { return meta[j - org]; } // per byte: class | PT_CONT | PT_CHUNK0
 };
 
 // ---------------------------------------------------------------- UTF-8 (Python's strict decoder)
@@ -57,15 +60,15 @@ YB_HD int pt_lead_len(uint8_t b) {
 
 // Decodes the character whose lead byte is at i; `end` = end of the chunk.  Returns its length, or 0 when the sequence is
 // malformed (truncated, bad continuation byte, overlong form, surrogate, > U+10FFFF): UnicodeDecodeError.start == i.
-YB_HD int pt_decode(const uint8_t *t, uint64_t i, uint64_t end, uint32_t *cp) {
-    const uint8_t b0 = t[i];
+YB_HD int pt_decode(const PtView &v, uint64_t i, uint64_t end, uint32_t *cp) {
+    const uint8_t b0 = v.T(i);
     const int len = pt_lead_len(b0);
     if (len == 0 || i + (uint64_t)len > end) return 0;
     if (len == 1) {
         *cp = b0;
         return 1;
     }
-    const uint8_t b1 = t[i + 1];
+    const uint8_t b1 = v.T(i + 1);
     uint8_t lo = 0x80, hi = 0xBF;
     if (b0 == 0xE0) lo = 0xA0;       // no overlong 3-byte forms
     else if (b0 == 0xED) hi = 0x9F;  // no surrogates
@@ -75,7 +78,7 @@ YB_HD int pt_decode(const uint8_t *t, uint64_t i, uint64_t end, uint32_t *cp) {
     uint32_t c = len == 2 ? (b0 & 0x1Fu) : len == 3 ? (b0 & 0x0Fu) : (b0 & 0x07u);
     c = (c << 6) | (b1 & 0x3Fu);
     for (int k = 2; k < len; ++k) {
-        const uint8_t bk = t[i + k];
+        const uint8_t bk = v.T(i + k);
         if ((bk & 0xC0) != 0x80) return 0;
         c = (c << 6) | (bk & 0x3Fu);
     }
@@ -84,31 +87,30 @@ YB_HD int pt_decode(const uint8_t *t, uint64_t i, uint64_t end, uint32_t *cp) {
 }
 
 // First pass, one call per byte: the meta byte (class / continuation), and whether Python's decoder would stop HERE
-// (the smallest such position over the text is UnicodeDecodeError.start).  chunk_first: this byte is a chunk's first;
-// chunk_end: end of this byte's chunk when it is known to be closer than 4 bytes, else any value >= i + 4.
-YB_HD uint8_t pt_classify(const uint8_t *t, uint64_t i, uint64_t chunk_end, bool chunk_first, const uint8_t *back_chunk0,
-                          const uint8_t *cls_table, bool *bad) {
-    const uint8_t b = t[i];
+// (the smallest such position over the text is UnicodeDecodeError.start).  v.meta holds only the PT_CHUNK0 marks at this
+// point.  chunk_end: end of this byte's chunk when it is closer than 4 bytes, else any value >= i + 4.
+YB_HD uint8_t pt_classify(const PtView &v, uint64_t i, uint64_t chunk_end, const uint8_t *cls_table, bool *bad) {
+    const uint8_t b = v.T(i);
     *bad = false;
     if ((b & 0xC0) == 0x80) {
         // a continuation byte is fine iff a lead byte at most 3 bytes back (inside this chunk) announces a sequence
         // that reaches it; a malformed sequence is reported by its lead byte (a smaller position)
         bool stray = true;
-        if (!chunk_first) {
+        if (!(v.M(i) & PT_CHUNK0)) {
             for (int d = 1; d <= 3 && (uint64_t)d <= i; ++d) {
-                const uint8_t p = t[i - d];
+                const uint8_t p = v.T(i - d);
                 if ((p & 0xC0) != 0x80) {
                     stray = pt_lead_len(p) <= d;
                     break;
                 }
-                if (back_chunk0[i - d] & PT_CHUNK0) break; // the chunk starts with continuation bytes
+                if (v.M(i - d) & PT_CHUNK0) break; // the chunk starts with continuation bytes
             }
         }
         *bad = stray;
         return PT_CONT | PT_O;
     }
     uint32_t cp = 0;
-    if (pt_decode(t, i, chunk_end, &cp) == 0) {
+    if (pt_decode(v, i, chunk_end, &cp) == 0) {
         *bad = true;
         return PT_O;
     }
@@ -116,18 +118,18 @@ YB_HD uint8_t pt_classify(const uint8_t *t, uint64_t i, uint64_t chunk_end, bool
 }
 
 // ---------------------------------------------------------------- token starts
-YB_HD bool pt_text_start(const PtView &v, uint64_t j, int64_t forced) { return (v.meta[j] & PT_CHUNK0) || (int64_t)j == forced; }
+YB_HD bool pt_text_start(const PtView &v, uint64_t j, int64_t forced) { return (v.M(j) & PT_CHUNK0) || (int64_t)j == forced; }
 
 // length of the character at j (valid text)
-YB_HD int pt_char_len(const PtView &v, uint64_t j) { return pt_lead_len(v.text[j]); }
+YB_HD int pt_char_len(const PtView &v, uint64_t j) { return pt_lead_len(v.T(j)); }
 
 // Contraction suffix after an apostrophe at p: 1 for s d m t, 2 for ll ve re, 0 for none (case-sensitive, inside the chunk).
 YB_HD int pt_contraction_len(const PtView &v, uint64_t p) {
-    if (v.text[p] != '\'' || p + 1 >= v.n || (v.meta[p + 1] & PT_CHUNK0)) return 0;
-    const uint8_t x = v.text[p + 1];
+    if (v.T(p) != '\'' || p + 1 >= v.n || (v.M(p + 1) & PT_CHUNK0)) return 0;
+    const uint8_t x = v.T(p + 1);
     if (x == 's' || x == 'd' || x == 'm' || x == 't') return 1;
-    if (p + 2 >= v.n || (v.meta[p + 2] & PT_CHUNK0)) return 0;
-    const uint8_t y = v.text[p + 2];
+    if (p + 2 >= v.n || (v.M(p + 2) & PT_CHUNK0)) return 0;
+    const uint8_t y = v.T(p + 2);
     if ((x == 'l' && y == 'l') || (x == 'v' && y == 'e') || (x == 'r' && y == 'e')) return 2;
     return 0;
 }
@@ -135,16 +137,16 @@ YB_HD int pt_contraction_len(const PtView &v, uint64_t p) {
 // The run rules alone (no contraction, no special): j is a character start and not the start of the text.
 YB_HD bool pt_base_start(const PtView &v, uint64_t j) {
     uint64_t prev = j - 1;
-    for (int k = 0; k < 3 && prev > 0 && (v.meta[prev] & PT_CONT); ++k) --prev; // (bounded: malformed text is reported, not followed)
-    const uint8_t c = v.meta[j] & PT_CLS, pc = v.meta[prev] & PT_CLS;
+    for (int k = 0; k < 3 && prev > 0 && (v.M(prev) & PT_CONT); ++k) --prev; // (bounded: malformed text is reported, not followed)
+    const uint8_t c = v.M(j) & PT_CLS, pc = v.M(prev) & PT_CLS;
     if (c != PT_S) {
         if (pc == c) return false;               // continues the run
-        return v.text[prev] != ' ';              // a U+0020 right before the run starts the token instead
+        return v.T(prev) != ' ';              // a U+0020 right before the run starts the token instead
     }
     if (pc != PT_S) return true;                 // first character of a whitespace run
     const uint64_t nx = j + (uint64_t)pt_char_len(v, j);
-    if (nx >= v.n || (v.meta[nx] & PT_CHUNK0)) return false; // the run reaches the end of the text: one token
-    return (v.meta[nx] & PT_CLS) != PT_S;        // last character of a run of >= 2, a non-space follows
+    if (nx >= v.n || (v.M(nx) & PT_CHUNK0)) return false; // the run reaches the end of the text: one token
+    return (v.M(nx) & PT_CLS) != PT_S;        // last character of a run of >= 2, a non-space follows
 }
 
 // Is the apostrophe-contraction at p taken?  `forced`: a position where a token is known to start (a special token ended
@@ -157,7 +159,7 @@ YB_HD bool pt_contraction_taken(const PtView &v, uint64_t p, int64_t forced) {
 // THE rule: does a pre-token start at byte j?  (forced = -1, or the end of a special token that was matched: the text
 // before it is consumed, a token starts there, and only apostrophes at or after it can open a contraction.)
 YB_HD bool pt_is_start(const PtView &v, uint64_t j, int64_t forced) {
-    if (v.meta[j] & PT_CONT) return false;
+    if (v.M(j) & PT_CONT) return false;
     if (pt_text_start(v, j, forced)) return true;
     // j - 1 exists and belongs to the same text.  Contractions reach at most 3 bytes to the right of their apostrophe.
     if (pt_contraction_taken(v, j - 1, forced)) return false; // first letter of the suffix
@@ -185,7 +187,7 @@ YB_HD uint32_t pt_special_at(const PtView &v, const PtSpecials &sp, uint64_t i) 
         if (len == 0 || i + len > v.n) continue;
         const uint8_t *w = sp.bytes + sp.off[s];
         bool eq = true;
-        for (uint32_t k = 0; k < len && eq; ++k) eq = v.text[i + k] == w[k] && (k == 0 || !(v.meta[i + k] & PT_CHUNK0));
+        for (uint32_t k = 0; k < len && eq; ++k) eq = v.T(i + k) == w[k] && (k == 0 || !(v.M(i + k) & PT_CHUNK0));
         if (eq) return s + 1;
     }
     return 0;
@@ -195,12 +197,12 @@ YB_HD uint32_t pt_special_len(const PtSpecials &sp, uint32_t occ) { return sp.of
 
 // An occurrence at i heads its chain iff no earlier occurrence (of the same chunk) reaches it: q + len(q) + 3 >= i.
 YB_HD bool pt_special_is_head(const PtView &v, const PtSpecials &sp, const uint8_t *occ, uint64_t i) {
-    if (v.meta[i] & PT_CHUNK0) return true;
+    if (v.M(i) & PT_CHUNK0) return true;
     const uint64_t window = (uint64_t)sp.max_len + 3;
     for (uint64_t d = 1; d <= window && d <= i; ++d) {
         const uint64_t q = i - d;
         if (occ[q] && (uint64_t)pt_special_len(sp, occ[q]) + 3 >= d) return false;
-        if (v.meta[q] & PT_CHUNK0) break; // nothing before the chunk's first byte matters
+        if (v.M(q) & PT_CHUNK0) break; // nothing before the chunk's first byte matters
     }
     return true;
 }
@@ -222,7 +224,7 @@ YB_HD void pt_special_walk(const PtView &v, const PtSpecials &sp, const uint8_t 
             cover = (int64_t)(q + len);
             // a token starts right after the match; redo the (at most 3) positions a contraction there can reach
             for (uint64_t j = (uint64_t)cover; j < (uint64_t)cover + 4 && j < v.n; ++j) {
-                if (v.meta[j] & PT_CHUNK0) break; // the next chunk is a text of its own
+                if (v.M(j) & PT_CHUNK0) break; // the next chunk is a text of its own
                 flags[j] = pt_is_start(v, j, cover) ? 1 : 0;
             }
         }
@@ -230,7 +232,7 @@ YB_HD void pt_special_walk(const PtView &v, const PtSpecials &sp, const uint8_t 
         uint64_t nq = q + 1;
         bool found = false;
         for (; nq <= reach && nq < v.n; ++nq) {
-            if (v.meta[nq] & PT_CHUNK0) break;
+            if (v.M(nq) & PT_CHUNK0) break;
             if (occ[nq]) {
                 found = true;
                 break;

@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
 }
 
 // Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
-// tile's signature (16 B per tile: length + the words holding bit(a), bit(b) and bit(a,b)); the tiles that may contain
+// tile's signature (12 B per tile: length + the 64-bit block that holds the pair's bits); the tiles that may contain
 // the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
 #ifdef YB_PROFILE_SCAN
 __device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];

@@ -6,9 +6,9 @@
 // offsets array by a two-level prefix sum.  All rules live in pretok_logic.h (shared with the CPU model the tests run
 // against regex.findall); the kernels only map bytes to threads.
 //
-// Passes over the text (all streaming, one thread per byte; the per-byte work is a few loads of neighbouring bytes that
-// hit L1/L2):   k_pt_classify  text -> meta (class, continuation, UTF-8 validation: first malformed byte by atomicMin)
-//               k_pt_starts    text, meta -> flags
+// Passes over the text:
+//               k_pt_fused     text -> meta (class, continuation, UTF-8 validation: first malformed byte by atomicMin)
+//                                      and flags, through an LDS window per workgroup
 //               k_pt_special_* text, meta -> occ -> corrected flags (only when special tokens are configured)
 //               k_pt_count / k_pt_scatter   flags -> offsets
 #pragma once
@@ -39,26 +39,102 @@ __global__ __launch_bounds__(BLOCK) void k_pt_mark_chunks(uint8_t *meta, const u
     if (c < n_chunks && chunk_off[c] < n) meta[chunk_off[c]] = PT_CHUNK0; // (meta was zeroed)
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pt_classify(PretokParams P) {
-    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK) {
-        const uint8_t own = P.meta[i] & PT_CHUNK0;
-        unsigned long long end = P.n;
-        for (unsigned long long k = i + 1; k < i + 4 && k < P.n; ++k)
-            if (P.meta[k] & PT_CHUNK0) { // (the only bit of a neighbour's meta byte this pass reads; it never changes)
-                end = k;
-                break;
+// classify + starts in one pass: a workgroup stages a window of the text (and the chunk marks) in LDS with a halo on both
+// sides, classifies every byte of window + halo there (neighbouring workgroups redo each other's halo: 16 bytes of 4 KiB),
+// then decides the start flag of every byte of the window from LDS.  The text is read from HBM once, meta and flags are
+// written once, 16 B per lane.  The rules are the same functions the CPU model runs, on an LDS view (PtView::org).
+constexpr int PT_WIN = BLOCK * 16; // bytes per workgroup and iteration
+constexpr int PT_HALO = 16;        // >= reach of the rules: 7 bytes back (contraction + previous character), 4 ahead
+constexpr int PT_LDS = PT_HALO + PT_WIN + PT_HALO;
+__global__ __launch_bounds__(BLOCK) void k_pt_fused(PretokParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[PT_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_meta[PT_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tmp[PT_LDS]; // classes, then flags
+    const unsigned long long n_win = (P.n + PT_WIN - 1) / PT_WIN;
+    const bool wide = (reinterpret_cast<uintptr_t>(P.text) & 15u) == 0; // 16-B loads need an aligned text buffer
+    for (unsigned long long w = blockIdx.x; w < n_win; w += gridDim.x) {
+        const unsigned long long base = w * PT_WIN;      // first byte of the window
+        const long long org = (long long)base - PT_HALO; // position of s_text[0] (negative for window 0)
+        // ---- stage: the window as 16-B pieces, the halos byte by byte
+        {
+            const unsigned long long g = base + (unsigned long long)threadIdx.x * 16;
+            uint8_t *dt = s_text + PT_HALO + threadIdx.x * 16, *dm = s_meta + PT_HALO + threadIdx.x * 16;
+            if (g + 16 <= P.n) {
+                if (wide) {
+                    *reinterpret_cast<uint4 *>(dt) = *reinterpret_cast<const uint4 *>(P.text + g);
+                } else {
+                    for (int k = 0; k < 16; ++k) dt[k] = P.text[g + k];
+                }
+                *reinterpret_cast<uint4 *>(dm) = *reinterpret_cast<const uint4 *>(P.meta + g);
+            } else {
+                for (int k = 0; k < 16; ++k) {
+                    dt[k] = g + k < P.n ? P.text[g + k] : 0;
+                    dm[k] = g + k < P.n ? P.meta[g + k] : 0;
+                }
             }
-        bool bad = false;
-        const uint8_t m = pt_classify(P.text, i, end, own != 0, P.meta, P.cls, &bad);
-        P.meta[i] = own | m;
-        if (bad) atomicMin(P.err, i);
+            if (threadIdx.x < 2 * PT_HALO) {
+                const int k = threadIdx.x < PT_HALO ? threadIdx.x : PT_WIN + threadIdx.x; // slot in s_text
+                const long long pos = org + k;
+                const bool in = pos >= 0 && (unsigned long long)pos < P.n;
+                s_text[k] = in ? P.text[pos] : 0;
+                s_meta[k] = in ? P.meta[pos] : 0;
+            }
+        }
+        __syncthreads();
+        // A view whose position `org` is s_text[0].  For window 0 the halo before the text does not exist: the view then
+        // starts at position 0 (s_text + PT_HALO) -- no rule looks before a chunk start, and position 0 is one.
+        const bool first = org < 0;
+        const unsigned long long vorg = first ? 0ull : (unsigned long long)org;
+        const PtView v{first ? s_text + PT_HALO : s_text, first ? s_meta + PT_HALO : s_meta, P.n, vorg};
+        uint8_t *tmp = first ? s_tmp + PT_HALO : s_tmp;   // tmp[pos - vorg]
+        uint8_t *meta_w = first ? s_meta + PT_HALO : s_meta;
+        // ---- classify the window + 8 bytes on each side (what the start rules can look at)
+        const long long c_lo = (long long)base - 8, c_hi = (long long)base + PT_WIN + 8; // [c_lo, c_hi)
+        {
+            unsigned long long bad_pos = ~0ull;
+            for (long long pos = c_lo + threadIdx.x; pos < c_hi; pos += BLOCK) { // (consecutive lanes, consecutive bytes)
+                if (pos < 0 || (unsigned long long)pos >= P.n) continue;
+                const unsigned long long i = (unsigned long long)pos;
+                unsigned long long end = P.n;
+                for (unsigned long long q = i + 1; q < i + 4 && q < P.n; ++q)
+                    if (v.M(q) & PT_CHUNK0) {
+                        end = q;
+                        break;
+                    }
+                bool bad = false;
+                tmp[i - vorg] = pt_classify(v, i, end, P.cls, &bad);
+                if (bad && i >= base && i < base + PT_WIN && i < bad_pos) bad_pos = i; // (a halo byte is reported by its own window)
+            }
+            if (bad_pos != ~0ull) atomicMin(P.err, bad_pos);
+        }
+        __syncthreads(); // every chunk mark has been read; now the class bits are added
+        for (long long pos = c_lo + threadIdx.x; pos < c_hi; pos += BLOCK) {
+            if (pos < 0 || (unsigned long long)pos >= P.n) continue;
+            const unsigned long long k = (unsigned long long)pos - vorg;
+            meta_w[k] = (uint8_t)((meta_w[k] & PT_CHUNK0) | tmp[k]);
+        }
+        __syncthreads();
+        // ---- start flags of the window (tmp is free again), then meta and flags go out as 16-B pieces
+        for (int k = threadIdx.x; k < PT_WIN; k += BLOCK) {
+            const unsigned long long j = base + k;
+            tmp[j - vorg] = j < P.n ? (pt_is_start(v, j, -1) ? 1 : 0) : 0;
+        }
+        __syncthreads();
+        {
+            const unsigned long long g = base + (unsigned long long)threadIdx.x * 16;
+            const uint8_t *fm = s_meta + PT_HALO + threadIdx.x * 16, *ff = s_tmp + PT_HALO + threadIdx.x * 16;
+            if (g + 16 <= P.n) {
+                *reinterpret_cast<uint4 *>(P.flags + g) = *reinterpret_cast<const uint4 *>(ff);
+                *reinterpret_cast<uint4 *>(P.meta + g) = *reinterpret_cast<const uint4 *>(fm);
+            } else {
+                for (int k = 0; k < 16 && g + k < P.n; ++k) {
+                    P.flags[g + k] = ff[k];
+                    P.meta[g + k] = fm[k];
+                }
+            }
+        }
+        __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_pt_starts(PretokParams P) {
-    const PtView v{P.text, P.meta, P.n};
-    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK)
-        P.flags[i] = pt_is_start(v, i, -1) ? 1 : 0;
 }
 
 // occurrences of the special tokens; a 256-bit set of their first bytes keeps nearly every thread out of the compare
@@ -163,7 +239,8 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
         const uint32_t grid = (uint32_t)std::min<unsigned long long>((n + BLOCK - 1) / BLOCK, 1u << 20);
         PretokParams P{text, meta, flags, occ, n, cls, err, sp_dev};
         hipLaunchKernelGGL(k_pt_mark_chunks, dim3((n_chunks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, meta, chunk_off, n_chunks, n);
-        hipLaunchKernelGGL(k_pt_classify, dim3(grid), dim3(BLOCK), 0, s, P);
+        const uint32_t wgrid = (uint32_t)std::min<unsigned long long>((n + PT_WIN - 1) / PT_WIN, 1u << 20);
+        hipLaunchKernelGGL(k_pt_fused, dim3(wgrid), dim3(BLOCK), 0, s, P);
         unsigned long long h_err = 0;
         if (hipMemcpyAsync(&h_err, err, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
         if (h_err != ~0ull) { // malformed UTF-8: nothing else is computed (the neighbour walks assume valid text)
@@ -171,7 +248,6 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
             rc = 0;
             break;
         }
-        hipLaunchKernelGGL(k_pt_starts, dim3(grid), dim3(BLOCK), 0, s, P);
         if (sp_dev.n) {
             hipLaunchKernelGGL(k_pt_special_find, dim3(grid), dim3(BLOCK), 0, s, P);
             hipLaunchKernelGGL(k_pt_special_resolve, dim3(grid), dim3(BLOCK), 0, s, P);
