@@ -208,11 +208,20 @@ int fail(yabpe_ctx *c, int code, const char *fmt, ...) {
                         rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "?", __FILE__, __LINE__); \
     } while (0)
 
+static bool trace_alloc_on() {
+    static const bool on = [] { const char *e = getenv("YABPE_TRACE_ALLOC"); return e && *e == '1'; }();
+    return on;
+}
+// YABPE_TRACE_ALLOC=1: every device allocation of the library goes to stderr (address range, element size) -- the map
+// that tells which buffer a "Memory access fault ... on address X" belongs to or lies next to.
 template <class T>
 int dmalloc(yabpe_ctx *c, T **p, uint64_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
     HIPCHK(c, hipMalloc((void **)p, n * sizeof(T)));
+    if (trace_alloc_on())
+        fprintf(stderr, "[yabpe alloc r%d] %p .. %p  %llu x %zu B\n", c ? c->rank : -1, (void *)*p, (void *)((char *)*p + n * sizeof(T)),
+                (unsigned long long)n, sizeof(T));
     return 0;
 }
 #define TRY(x)               \
@@ -222,6 +231,7 @@ int dmalloc(yabpe_ctx *c, T **p, uint64_t n) {
     } while (0)
 
 void dfree(void *p) {
+    if (p && trace_alloc_on()) fprintf(stderr, "[yabpe free] %p\n", p);
     if (p) (void)hipFree(p);
 }
 
@@ -1291,7 +1301,13 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 const bool delta_full = h->halt == HALT_DELTA_FULL;
                 h->halt = 0; h->halt_req = 0;
                 TRY(state_push(c));
-                if (delta_full) TRY(comm_buffers(c, c->xcap * 4));
+                if (delta_full) {  // more distinct pairs changed in one merge than a rank can hold / send: 4x of both
+                    TRY(comm_buffers(c, c->xcap * 4));
+                    const uint64_t dcap = std::min<uint64_t>((uint64_t)c->delta.cap * 4, 1ull << 24);
+                    table_free(c->delta);
+                    HIPCHK(c, hipMemsetAsync(&c->st->delta_entries, 0, 8, c->stream));
+                    TRY(table_alloc(c, c->delta, dcap, &c->st->delta_entries));
+                }
                 TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
                 TRY(state_pull(c));
                 i = h->iter - rec_base;  // resume after the last recorded merge
@@ -1656,10 +1672,10 @@ static int comm_attach(yabpe_ctx *c, int rank, int n_ranks) {
     return 0;
 }
 static int comm_finish(yabpe_ctx *c) {
-    const uint64_t dcap = 1ull << optv(c, "delta_table_log2", 14);
+    const uint64_t dcap = 1ull << optv(c, "delta_table_log2", 16);
     TRY(table_alloc(c, c->delta, dcap, &c->st->delta_entries));
     TRY(dmalloc(c, &c->xsmall, (uint64_t)c->n_ranks));
-    TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 2048)));
+    TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 4096)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return YABPE_OK;
 }

@@ -203,7 +203,8 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
         }
         s = pt_next(t, s);
     }
-    atomicMax(&st->halt_req, (uint32_t)HALT_TABLE_FULL);
+    // (a per-rank delta table that runs out of probes is grown together with the exchange buffers, not the replica)
+    atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
 }
 
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
