@@ -1039,7 +1039,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     c->blk_used = 0;  // the selection folds and clears them; what follows counts this merge's grids
     bool selected = false;
     if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
-        const bool fuse = optv(c, "fuse_select", 1) != 0;
+        const bool fuse = optv(c, "fuse_select", c->multi ? 0 : 1) != 0;  // (several ranks: the plain two-launch form; the hand-over saves < 1 us there)
         CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;
