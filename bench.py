@@ -240,8 +240,19 @@ def main() -> None:
                 dt = time.perf_counter() - t1
                 pt.pretokenize_free()
                 best = dt if best is None else min(best, dt)
+            cpu_pt = None
+            if not args.no_cpu_baseline:  # what the reference runs for this step: regex.findall, one core, on a bounded sample
+                from oracle import pretok
+
+                sample = pt.d2h(tb, min(tn, 16 << 20)).tobytes()
+                sample = sample[: sample.rfind(b" ")]
+                t1 = time.perf_counter()
+                n_cpu = len(pretok.pretokenize(sample, ["<|endoftext|>"]))
+                dt = time.perf_counter() - t1
+                cpu_pt = {"MB_per_sec": round(len(sample) / dt / 1e6, 2), "cores": 1, "kind": "reference dependency (regex.findall)",
+                          "sample": f"first {len(sample)} bytes of the same text, {n_cpu} pre-tokens in {dt:.2f} s"}
             out["pretokenize"] = {"GB_per_sec": round(tn / best / 1e9, 2), "ms": round(best * 1e3, 2), "text_bytes": tn, "pretokens": nw_pt,
-                                  "equals_generator_words": bool(nw_pt == tw),
+                                  "equals_generator_words": bool(nw_pt == tw), "cpu_baseline": cpu_pt,
                                   "note": "yabpe_pretokenize (UTF-8 validation + GPT-2 split + special tokens -> word offsets in HBM), "
                                           "wall time incl. scratch allocation, best of 3; not part of `value`"}
     if rank == 0 and not args.no_cpu_baseline:

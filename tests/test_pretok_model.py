@@ -53,14 +53,10 @@ def model_split(lib, data: bytes, specials=(), chunk_starts=(0,)):
 
 
 def regex_split(data: bytes, specials=(), chunk_starts=(0,)):
-    pat = GPT2
-    if specials:
-        pat = "|".join(regex.escape(s) for s in specials) + "|" + pat
-    out = []
-    bounds = list(chunk_starts) + [len(data)]
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        out += [t.encode("utf-8") for t in regex.findall(pat, data[a:b].decode("utf-8")) if t]
-    return out
+    """The oracle of this step: regex.findall with the reference's pattern (oracle/pretok.py)."""
+    from oracle import pretok
+
+    return pretok.pretokenize(data, specials, chunk_starts)
 
 
 EDGE = [
