@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -331,7 +332,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     const uint64_t words = ((uint64_t)c->table.cap + 31) / 32 + 1;
     HIPCHK(c, hipMemsetAsync(c->table.touched, 0, words * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
-    CandState h{best_count - best_count / 5, 0u, 0u};
+    CandState h{best_count - best_count / 5, 0u, 0u, 0u, 0u};
     HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     CandParams P{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, nullptr, SelectParams{}};
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
@@ -341,6 +342,10 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cand_rebuilds++;
     c->use_cand = !h.overflow && h.n < CAND_CAP / 2;
+    // the list is complete: publish its length (k_argmax_cand reads n_seen, never the moving n)
+    const uint32_t seen = std::min<uint32_t>(h.n, CAND_CAP);
+    HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->cand_state) + offsetof(CandState, n_seen), &seen, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1039,7 +1044,7 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     c->blk_used = 0;  // the selection folds and clears them; what follows counts this merge's grids
     bool selected = false;
     if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
-        const bool fuse = optv(c, "fuse_select", c->multi ? 0 : 1) != 0;  // (several ranks: the plain two-launch form; the hand-over saves < 1 us there)
+        const bool fuse = optv(c, "fuse_select", 1) != 0;
         CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;

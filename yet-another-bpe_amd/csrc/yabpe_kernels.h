@@ -105,10 +105,13 @@ __device__ __forceinline__ Best best_load_coherent(const Best *p) {
 }
 
 // candidate argmax state (see k_argmax_cand)
+constexpr uint32_t CAND_CAP = 1u << 16; // capacity of the candidate list
 struct CandState {
     unsigned long long T;
     uint32_t n, overflow;
-};
+    uint32_t n_seen; // entries of cand[] that were complete when the last selection ran: what the NEXT argmax may read.
+    uint32_t pad;    // (n itself moves while k_argmax_cand runs -- a workgroup that starts late would otherwise read
+};                   //  slots another workgroup has counted but not stored yet)
 
 // multi-GPU delta exchange records (see k_delta_extract)
 struct DeltaHdr {
@@ -1878,7 +1881,7 @@ struct SelectParams {
     DeltaHdr *delta_hdr;                // multi-GPU: this rank's send header (count reset here), else NULL
     unsigned long long *blk_stats;      // per-workgroup counters of the last k_apply
     uint32_t n_blk;
-    const CandState *cs;                // != NULL: the partials come from k_argmax_cand
+    CandState *cs;                      // != NULL: the partials come from k_argmax_cand
 };
 
 // Adds the per-workgroup counters of the last apply pass to DevState and clears them (one workgroup).
@@ -1944,6 +1947,8 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
         if (P.cs) {
             candT = P.cs->T;
             cand_over = __hip_atomic_load(&P.cs->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every workgroup of the argmax has finished (kernel boundary, or its ticket): the list is complete up to n
+            P.cs->n_seen = min(__hip_atomic_load(&P.cs->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), CAND_CAP);
         }
         s_fold[0] = 0;
         s_fold[1] = 0;
@@ -2235,7 +2240,6 @@ __global__ __launch_bounds__(BLOCK) void k_sum_u32(const uint32_t *p, unsigned l
 // So max over (cand U touched) is the true maximum -- with all its ties -- whenever that maximum is >= T.  If it is
 // not (the best count decayed below T, or cand[] overflowed), k_select stops with HALT_RESCAN and the host finishes
 // the batch with the full scan.  The best count is non-increasing over merges, so T is refreshed about every 64.
-constexpr uint32_t CAND_CAP = 1u << 16;
 struct CandParams {
     PairTable table;
     const uint32_t *rank;
@@ -2265,7 +2269,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
 #endif
     const uint32_t stop = P.st->done | P.st->halt; // (these three loads do not depend on each other: one round trip)
     const unsigned long long T = P.cs->T;
-    const uint32_t n0 = min(P.cs->n, CAND_CAP);
+    const uint32_t n0 = min(P.cs->n_seen, CAND_CAP); // (not n: see CandState)
     if (!stop) {
         Best best{0ull, 0u, EMPTY, 0u, 0u};
         const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
