@@ -8,7 +8,7 @@ OUT=gpurun_out/pmc
 rm -rf $OUT && mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-include-regex "k_scan" --output-format csv -d $OUT/$C -- \
-    python3 bench.py --no-cpu-baseline --no-dedup-line --merges 2500 --roofline-merges 2500 "$@" > $OUT/bench_$C.json 2> $OUT/$C.err
+    python3 bench.py --no-cpu-baseline --no-dedup-line --no-pretok-line --merges 2500 --roofline-merges 2500 "$@" > $OUT/bench_$C.json 2> $OUT/$C.err
 done
 python3 - <<'PY'
 import csv, glob, json
