@@ -159,7 +159,7 @@ def test_many_tiles_retile_and_table_growth():
     assert s2["retiles"] >= 1
     # the plain streaming scan (skip index off) and the always-split / never-split forms give the same result
     for opts in ({"skip_index": 0}, {"split": 1}, {"split": 0}, {"sig_rebuild_every": 3, "check_interval": 2}, {"fuse_skip": 1}, {"inline_single": 0}, {"rank_rides": 0}, {"dense_worklist": 1}, {"dense_worklist": 0}, {"cand_argmax": 0}, {"cand_min_count": 1, "check_interval": 3},
-                 {"fuse_select": 0}, {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
+                 {"fuse_select": 0}, {"cand_rebuild_every": 1}, {"cand_rebuild_every": 100000, "check_interval": 8}, {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
                  {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16}):
         v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
         assert (v3, m3) == (exp_vocab, exp_merges), opts

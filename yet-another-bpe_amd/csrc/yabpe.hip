@@ -160,6 +160,7 @@ struct yabpe_ctx {
     bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
     // candidate argmax
     CandState *cand_state = nullptr;
+    uint32_t cand_built_at = 0;      // merge index (of this yabpe_train call) at which cand[] was last rebuilt
     uint32_t *sel_ticket = nullptr;  // k_argmax_cand: finished-workgroup counter (the last one selects; resets itself)
     uint32_t *cand = nullptr;
     bool use_cand = false;
@@ -1253,7 +1254,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->use_cand = false;
             skip_cand_once = false;
         } else if (h->iter > rec_base) {
-            TRY(cand_rebuild(c, h->best_count));
+            // The list stays exact for as long as the maximum stays >= its threshold T (slots that rise are appended by
+            // the argmax itself), so it is rebuilt -- a scan of the whole table -- only now and then: when there is none
+            // (start, table rebuilt or grown, fallback), and every `cand_rebuild_every` merges to keep it short.
+            const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "cand_rebuild_every", 512));
+            if (!c->use_cand || i - c->cand_built_at >= every) {
+                TRY(cand_rebuild(c, h->best_count));
+                c->cand_built_at = i;
+            }
         }
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
