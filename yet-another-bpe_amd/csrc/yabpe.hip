@@ -1243,12 +1243,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         const int64_t split_opt = optv(c, "split", -1);  // -1 auto, 0 never, 1 always
         if (split_opt >= 0)
             c->split_mode = split_opt == 1;
-        else if (!c->split_mode && h->iter > rec_base && h->best_count * 2 < c->n_tiles)
+        else if (!c->split_mode && h->iter > rec_base && h->best_count * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
             c->split_mode = true;
         {
             const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
             const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
-            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < (double)optv(c, "dense_multi", 2048));
+            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < (double)optv(c, "dense_multi", 1ll << 40));
         }
         if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
             c->use_cand = false;
