@@ -1243,7 +1243,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         const int64_t split_opt = optv(c, "split", -1);  // -1 auto, 0 never, 1 always
         if (split_opt >= 0)
             c->split_mode = split_opt == 1;
-        else if (!c->split_mode && h->iter > rec_base && h->best_count * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
+        // (pooled words: the count is weighted, what matters is how many resident sites the last merge had)
+        else if (!c->split_mode && h->iter > rec_base &&
+                 (c->weighted && h->sites ? h->sites : h->best_count) * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
             c->split_mode = true;
         {
             const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;

@@ -222,34 +222,62 @@ __global__ void k_word_hash(const uint8_t *bytes, const unsigned long long *off,
 }
 
 // rep[w] = index of the representative (first inserter) of w's byte string; count[rep] += freq(w)
-__global__ void k_word_dedup(const uint8_t *bytes, const unsigned long long *off, const unsigned long long *freq,
-                             unsigned long long n, const unsigned long long *hash, uint32_t *slots, unsigned long long mask,
-                             uint32_t *rep, unsigned long long *count) {
-    const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n) return;
-    const unsigned long long h = hash[w];
-    const unsigned long long o0 = off[w], L = off[w + 1] - o0;
-    unsigned long long s = h & mask;
-    uint32_t r = EMPTY;
-    while (true) {
-        uint32_t cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY) {
-            cur = atomicCAS(&slots[s], EMPTY, (uint32_t)w);
-            if (cur == EMPTY) { r = (uint32_t)w; break; }
-        }
-        if (hash[cur] == h) {
-            const unsigned long long c0 = off[cur];
-            if (off[cur + 1] - c0 == L) {
-                bool eq = true;
-                for (unsigned long long i = 0; i < L; ++i)
-                    if (bytes[c0 + i] != bytes[o0 + i]) { eq = false; break; }
-                if (eq) { r = cur; break; }
-            }
-        }
-        s = (s + 1) & mask;
+// Every word finds (or becomes) the representative of its byte string in an open-addressing set of word indices, and
+// adds its frequency to the representative's count.  Word frequencies are Zipfian -- the most common word of a 1 GiB
+// corpus occurs ~10 M times -- and same-address HBM atomics serialise (~11 ns each), so the counts are first summed
+// per workgroup in a small LDS table: a hot word then costs one HBM atomic per workgroup, not one per occurrence.
+constexpr int DEDUP_AGG = 512;
+__global__ __launch_bounds__(256) void k_word_dedup(const uint8_t *bytes, const unsigned long long *off, const unsigned long long *freq,
+                                                    unsigned long long n, const unsigned long long *hash, uint32_t *slots, unsigned long long mask,
+                                                    uint32_t *rep, unsigned long long *count) {
+    __shared__ uint32_t s_k[DEDUP_AGG];
+    __shared__ unsigned long long s_v[DEDUP_AGG];
+    for (int i = threadIdx.x; i < DEDUP_AGG; i += 256) {
+        s_k[i] = EMPTY;
+        s_v[i] = 0ull;
     }
-    rep[w] = r;
-    atomicAdd(&count[r], freq ? freq[w] : 1ull);
+    __syncthreads();
+    const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n) {
+        const unsigned long long h = hash[w];
+        const unsigned long long o0 = off[w], L = off[w + 1] - o0;
+        unsigned long long s = h & mask;
+        uint32_t r = EMPTY;
+        while (true) {
+            uint32_t cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == EMPTY) {
+                cur = atomicCAS(&slots[s], EMPTY, (uint32_t)w);
+                if (cur == EMPTY) { r = (uint32_t)w; break; }
+            }
+            if (hash[cur] == h) {
+                const unsigned long long c0 = off[cur];
+                if (off[cur + 1] - c0 == L) {
+                    bool eq = true;
+                    for (unsigned long long i = 0; i < L; ++i)
+                        if (bytes[c0 + i] != bytes[o0 + i]) { eq = false; break; }
+                    if (eq) { r = cur; break; }
+                }
+            }
+            s = (s + 1) & mask;
+        }
+        rep[w] = r;
+        const unsigned long long f = freq ? freq[w] : 1ull;
+        uint32_t a = hash32(r) & (DEDUP_AGG - 1);
+        bool done = false;
+        for (int probe = 0; probe < 8 && !done; ++probe) {
+            uint32_t k = __hip_atomic_load(&s_k[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == EMPTY) k = atomicCAS(&s_k[a], EMPTY, r);
+            if (k == EMPTY || k == r) {
+                atomicAdd(&s_v[a], f);
+                done = true;
+            }
+            a = (a + 1) & (DEDUP_AGG - 1);
+        }
+        if (!done) atomicAdd(&count[r], f); // the LDS table is crowded around this hash: straight to HBM
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DEDUP_AGG; i += 256)
+        if (s_k[i] != EMPTY && s_v[i]) atomicAdd(&count[s_k[i]], s_v[i]);
 }
 
 __global__ void k_dedup_flags(const uint32_t *rep, const unsigned long long *off, unsigned long long n, uint32_t *flag, uint32_t *ulen) {
