@@ -1057,7 +1057,9 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
     RankParams R{c->tt, c->st};
     const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
     // lexrank maintenance rides on the k_scan_skip launch when that form is used (one dependent launch fewer)
-    const bool rank_rides = c->n_tiles && c->split_mode && c->sig && c->sig_valid && !optv(c, "fuse_skip", 0) && optv(c, "rank_rides", 1);
+    // ... and on the fused k_apply launch
+    const bool rank_rides = c->n_tiles && optv(c, "rank_rides", 1) &&
+                            (c->split_mode ? (c->sig && c->sig_valid && !optv(c, "fuse_skip", 0)) : true);
     if (!rank_rides) hipLaunchKernelGGL(k_rank_update, dim3(rank_blocks), dim3(BLOCK), 0, c->stream, R);
     const PairTable out_table = c->multi ? c->delta : c->table;
     if (ev) {
@@ -1070,9 +1072,9 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         if (!c->split_mode) {
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
-                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R);
             else
-                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid), dim3(BLOCK), 0, c->stream, P);
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
             // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed

@@ -975,62 +975,6 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
     agg_flush(agg, P.out, st);
 }
 
-// ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
-// (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
-template <bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P) {
-    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    __shared__ uint32_t s_keys[AGG_N];
-    __shared__ AggV s_vals[AGG_N];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
-    __shared__ unsigned long long s_cnt[2];
-
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    C.mk = yb_memkey(C.a, C.b);
-    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
-    const uint32_t mk = C.mk;
-    agg_init(C.agg);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    WaveLds &W = s_w[wib];
-    wave_lds_init(W, lane);
-    __syncthreads();
-
-    unsigned long long wave_sites = 0; // wave-uniform
-    unsigned long long wave_freed = 0; // slots removed from this wave's tiles
-    const uint32_t stride = gridDim.x * WPB;
-    const uint32_t n_tiles = P.n_tiles;
-    // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
-    // next tile's 2 x 16 B per lane are in flight while the current tile is examined.
-    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
-        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
-        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
-        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
-        TileRegs nxt = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t tile = batch + i * stride;
-            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
-            const TileRegs r = nxt;
-            if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
-            if (len == 0) continue;
-            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
-        }
-    }
-#ifdef YB_PROFILE_SLOW
-    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
-#endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
-}
-
 // ---------------------------------------------------------------- split form, pass 1: pure streaming scan
 // Reads the live token stream once (the roofline pass) and records which tiles contain the pair.  No LDS
 // tables, few registers; every workgroup appends to its own segment of the worklist: no global atomics.
@@ -1171,6 +1115,67 @@ __device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t 
 }
 
 __global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) { rank_update_block(P, blockIdx.x); }
+
+// ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
+// (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
+template <bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R) {
+    // workgroups [0, apply_blocks) apply the merge; the rest of the grid does k_rank_update's work in the same launch
+    if (blockIdx.x >= apply_blocks) {
+        rank_update_block(R, blockIdx.x - apply_blocks);
+        return;
+    }
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
+    __shared__ unsigned long long s_cnt[2];
+
+    DevState *st = P.st;
+    if (st->done | st->halt) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
+    const uint32_t mk = C.mk;
+    agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    WaveLds &W = s_w[wib];
+    wave_lds_init(W, lane);
+    __syncthreads();
+
+    unsigned long long wave_sites = 0; // wave-uniform
+    unsigned long long wave_freed = 0; // slots removed from this wave's tiles
+    const uint32_t stride = apply_blocks * WPB;
+    const uint32_t n_tiles = P.n_tiles;
+    // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
+    // next tile's 2 x 16 B per lane are in flight while the current tile is examined.
+    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
+        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
+        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
+        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
+        TileRegs nxt = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t tile = batch + i * stride;
+            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
+            const TileRegs r = nxt;
+            if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
+            if (len == 0) continue;
+            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+        }
+    }
+#ifdef YB_PROFILE_SLOW
+    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
+#endif
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+}
 
 // ---------------------------------------------------------------- skip index: signatures and the scan that uses them
 struct SigParams {
