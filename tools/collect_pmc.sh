@@ -16,10 +16,13 @@ def load(c):
     f = glob.glob(f"gpurun_out/pmc/{c}/*/*counter_collection.csv")[0]
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("yb::k_scan(") and r["Counter_Name"] == c]
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
+n_all = len(f)
+f = [x for x in f if x > 64.0]   # launches after the stop flag do nothing (< 1 us, no traffic): not part of the average,
+w = w[:len(f)] if len(w) >= len(f) else w   # as they are not part of bench.py's timed average either
 rf = json.load(open("gpurun_out/pmc/bench_FETCH_SIZE.json"))["roofline"]  # k_scan of the auxiliary pass
 mf, mw = sum(f) / len(f), sum(w) / len(w)
 traffic = 2 * mf * 1024 + mw * 1024
-out = {"kernel": "yb::k_scan", "dispatches": len(f), "mean_FETCH_SIZE_KiB": mf, "mean_WRITE_SIZE_KiB": mw,
+out = {"kernel": "yb::k_scan", "dispatches": len(f), "dispatches_incl_noop": n_all, "mean_FETCH_SIZE_KiB": mf, "mean_WRITE_SIZE_KiB": mw,
        "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2; unit KiB -> x1024",
        "traffic_bytes_per_launch": traffic, "algo_bytes_per_launch_same_run": rf["algo_bytes_per_launch"],
        "actual_stream_bytes_per_launch_same_run": rf["actual_stream_bytes_per_launch"],

@@ -161,6 +161,7 @@ struct yabpe_ctx {
     // candidate argmax
     CandState *cand_state = nullptr;
     uint32_t cand_built_at = 0;      // merge index (of this yabpe_train call) at which cand[] was last rebuilt
+    unsigned long long cand_best_at_build = 0;
     uint32_t *sel_ticket = nullptr;  // k_argmax_cand: finished-workgroup counter (the last one selects; resets itself)
     uint32_t *cand = nullptr;
     bool use_cand = false;
@@ -1262,9 +1263,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // the argmax itself), so it is rebuilt -- a scan of the whole table -- only now and then: when there is none
             // (start, table rebuilt or grown, fallback), and every `cand_rebuild_every` merges to keep it short.
             const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "cand_rebuild_every", 512));
-            if (!c->use_cand || i - c->cand_built_at >= every) {
+            // ... and before the maximum gets close to T (0.8 x the best count at build time): a fallback costs the rest
+            // of a batch.  Early in a run the best count falls by more than that per batch, so the list is rebuilt every
+            // batch there; late in the run hardly ever.
+            const bool near_T = h->best_count * 100 < c->cand_best_at_build * 92;  // T = 0.80, margin up to 0.92
+            if (!c->use_cand || i - c->cand_built_at >= every || near_T) {
                 TRY(cand_rebuild(c, h->best_count));
                 c->cand_built_at = i;
+                c->cand_best_at_build = h->best_count;
             }
         }
         if (c->split_mode && optv(c, "skip_index", 1)) {
@@ -1309,6 +1315,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->cand_rescans++;
             skip_cand_once = true;
             i = h->iter - rec_base;
+            while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;  // those launches did nothing: timed again in the re-run
             continue;
         }
         if (h->halt) {
@@ -1328,6 +1335,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
                 TRY(state_pull(c));
                 i = h->iter - rec_base;  // resume after the last recorded merge
+                while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;
                 continue;
             }
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
