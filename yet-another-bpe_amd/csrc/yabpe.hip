@@ -163,7 +163,7 @@ struct yabpe_ctx {
     uint32_t cand_built_at = 0;      // merge index (of this yabpe_train call) at which cand[] was last rebuilt
     unsigned long long cand_best_at_build = 0;
     uint32_t *sel_ticket = nullptr;  // k_argmax_cand: finished-workgroup counter (the last one selects; resets itself)
-    uint32_t *cand = nullptr;
+    uint2 *cand = nullptr;
     bool use_cand = false;
     uint64_t cand_rebuilds = 0, cand_rescans = 0;
     // multi-GPU

@@ -2251,7 +2251,7 @@ struct CandParams {
     Best *partials;
     DevState *st;
     CandState *cs;
-    uint32_t *cand;
+    uint2 *cand;       // (slot, key) of every candidate: the key rides along so that count and ranks are one round trip
     uint32_t *ticket;  // != NULL: the last workgroup to finish runs the selection itself (no k_select launch)
     SelectParams sel;
 };
@@ -2278,7 +2278,14 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     if (!stop) {
         Best best{0ull, 0u, EMPTY, 0u, 0u};
         const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
-        for (uint32_t i = tid; i < n0; i += nth) cand_eval(P, P.cand[i], best);
+        for (uint32_t i = tid; i < n0; i += nth) {
+            const uint2 e = P.cand[i]; // a slot keeps its key for as long as the table lives
+            const long long cn = (long long)P.table.cnt[e.x];
+            const uint32_t rl = P.rank[e.y >> 16], rr = P.rank[e.y & 0xffffu];
+            if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
+            const Best b{(unsigned long long)cn, (rl << 16) | rr, e.y, e.x, 0u};
+            if (best_gt(b, best)) best = b;
+        }
         const uint32_t words = (P.table.cap + 31) >> 5;
         for (uint32_t w = tid; w < words; w += nth) {
             uint32_t bits = P.table.touched[w];
@@ -2292,7 +2299,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
                     const uint32_t bit = 1u << (s & 31);
                     if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
                         const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-                        if (idx < CAND_CAP) P.cand[idx] = s; else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -2333,7 +2340,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
         if (cn <= 0 || (unsigned long long)cn < T) continue;
         atomicOr(&P.table.incand[s >> 5], 1u << (s & 31));
         const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-        if (idx < CAND_CAP) P.cand[idx] = s; else P.cs->overflow = 1u;
+        if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else P.cs->overflow = 1u;
     }
 }
 
