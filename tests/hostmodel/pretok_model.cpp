@@ -49,10 +49,11 @@ extern "C" int pretok_model(const uint8_t *text, uint64_t n, const uint64_t *chu
         uint32_t max_len = 0;
         for (uint32_t s = 0; s < n_sp; ++s) max_len = sp_off[s + 1] - sp_off[s] > max_len ? sp_off[s + 1] - sp_off[s] : max_len;
         PtSpecials sp{sp_bytes, sp_off, n_sp, max_len};
-        std::vector<uint8_t> occ(n, 0);
-        for (uint64_t i = 0; i < n; ++i) occ[i] = (uint8_t)pt_special_at(v, sp, i);
-        for (uint64_t i = 0; i < n; ++i)
-            if (occ[i] && pt_special_is_head(v, sp, occ.data(), i)) pt_special_walk(v, sp, occ.data(), flags_out, i);
+        auto occ = [&](uint64_t q) -> uint32_t { return pt_special_at(v, sp, q); };
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t o = occ(i);
+            if (o && pt_special_is_head(v, sp, occ, i)) pt_special_walk(v, sp, occ, flags_out, i, o);
+        }
     }
     return 0;
 }

@@ -195,25 +195,32 @@ YB_HD uint32_t pt_special_at(const PtView &v, const PtSpecials &sp, uint64_t i) 
 
 YB_HD uint32_t pt_special_len(const PtSpecials &sp, uint32_t occ) { return sp.off[occ] - sp.off[occ - 1]; }
 
+// Occurrences are looked up on demand (occ(q) = pt_special_at at q, usually behind a first-byte filter): they are rare,
+// so no per-byte occurrence array is kept.
+
 // An occurrence at i heads its chain iff no earlier occurrence (of the same chunk) reaches it: q + len(q) + 3 >= i.
-YB_HD bool pt_special_is_head(const PtView &v, const PtSpecials &sp, const uint8_t *occ, uint64_t i) {
+template <class OccF>
+YB_HD bool pt_special_is_head(const PtView &v, const PtSpecials &sp, OccF occ, uint64_t i) {
     if (v.M(i) & PT_CHUNK0) return true;
     const uint64_t window = (uint64_t)sp.max_len + 3;
     for (uint64_t d = 1; d <= window && d <= i; ++d) {
         const uint64_t q = i - d;
-        if (occ[q] && (uint64_t)pt_special_len(sp, occ[q]) + 3 >= d) return false;
+        const uint32_t o = occ(q);
+        if (o && (uint64_t)pt_special_len(sp, o) + 3 >= d) return false;
         if (v.M(q) & PT_CHUNK0) break; // nothing before the chunk's first byte matters
     }
     return true;
 }
 
-// Resolves the chain headed by the occurrence at i, left to right, and writes the flags it changes.
-YB_HD void pt_special_walk(const PtView &v, const PtSpecials &sp, const uint8_t *occ, uint8_t *flags, uint64_t i) {
+// Resolves the chain headed by the occurrence `o0` at i, left to right, and writes the flags it changes.
+template <class OccF>
+YB_HD void pt_special_walk(const PtView &v, const PtSpecials &sp, OccF occ, uint8_t *flags, uint64_t i, uint32_t o0) {
     int64_t cover = -1;        // end of the last special that was taken
     uint64_t q = i;
+    uint32_t oq = o0;
     uint64_t reach = i;        // last byte an occurrence of this chain can influence
     while (true) {
-        const uint32_t len = pt_special_len(sp, occ[q]);
+        const uint32_t len = pt_special_len(sp, oq);
         if (q + len + 3 > reach) reach = q + len + 3;
         bool taken;
         if (cover >= 0 && (int64_t)q < cover) taken = false;            // inside the previous match
@@ -230,15 +237,14 @@ YB_HD void pt_special_walk(const PtView &v, const PtSpecials &sp, const uint8_t 
         }
         // next occurrence of the chain
         uint64_t nq = q + 1;
-        bool found = false;
+        uint32_t no = 0;
         for (; nq <= reach && nq < v.n; ++nq) {
             if (v.M(nq) & PT_CHUNK0) break;
-            if (occ[nq]) {
-                found = true;
-                break;
-            }
+            no = occ(nq);
+            if (no) break;
         }
-        if (!found) return;
+        if (!no) return;
         q = nq;
+        oq = no;
     }
 }

@@ -9,7 +9,7 @@
 // Passes over the text:
 //               k_pt_fused     text -> meta (class, continuation, UTF-8 validation: first malformed byte by atomicMin)
 //                                      and flags, through an LDS window per workgroup
-//               k_pt_special_* text, meta -> occ -> corrected flags (only when special tokens are configured)
+//               k_pt_special   text, meta -> corrected flags (only when special tokens are configured)
 //               k_pt_count / k_pt_scatter   flags -> offsets
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,7 +26,6 @@ struct PretokParams {
     const uint8_t *text;
     uint8_t *meta;
     uint8_t *flags;
-    uint8_t *occ;
     unsigned long long n;
     const uint8_t *cls;       // class per code point (0x110000 entries)
     unsigned long long *err;  // smallest malformed byte position (atomicMin), ~0 = none
@@ -137,8 +136,10 @@ __global__ __launch_bounds__(BLOCK) void k_pt_fused(PretokParams P) {
     }
 }
 
-// occurrences of the special tokens; a 256-bit set of their first bytes keeps nearly every thread out of the compare
-__global__ __launch_bounds__(BLOCK) void k_pt_special_find(PretokParams P) {
+// Special tokens: one pass.  A 256-bit set of the specials' first bytes keeps nearly every thread out of the compare;
+// a thread that finds an occurrence checks whether it heads its chain (occurrences before it are looked up on demand,
+// through the same filter) and, if so, resolves the whole chain (pretok_logic.h).
+__global__ __launch_bounds__(BLOCK) void k_pt_special(PretokParams P) {
     __shared__ uint32_t s_first[8];
     if (threadIdx.x < 8) s_first[threadIdx.x] = 0u;
     __syncthreads();
@@ -147,19 +148,17 @@ __global__ __launch_bounds__(BLOCK) void k_pt_special_find(PretokParams P) {
         if (P.sp.off[threadIdx.x + 1] > o) atomicOr(&s_first[P.sp.bytes[o] >> 5], 1u << (P.sp.bytes[o] & 31));
     }
     __syncthreads();
-    const PtView v{P.text, P.meta, P.n};
+    const PtView v{P.text, P.meta, P.n, 0};
+    const PtSpecials sp = P.sp;
+    const uint32_t *first = s_first;
+    auto occ = [&](unsigned long long q) -> uint32_t {
+        const uint8_t b = v.T(q);
+        return ((first[b >> 5] >> (b & 31)) & 1u) ? pt_special_at(v, sp, q) : 0u;
+    };
     for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK) {
-        const uint8_t b = P.text[i];
-        uint32_t o = 0;
-        if ((s_first[b >> 5] >> (b & 31)) & 1u) o = pt_special_at(v, P.sp, i);
-        P.occ[i] = (uint8_t)o;
+        const uint32_t o = occ(i);
+        if (o && pt_special_is_head(v, sp, occ, i)) pt_special_walk(v, sp, occ, P.flags, i, o);
     }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_pt_special_resolve(PretokParams P) {
-    const PtView v{P.text, P.meta, P.n};
-    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += (unsigned long long)gridDim.x * BLOCK)
-        if (P.occ[i] && pt_special_is_head(v, P.sp, P.occ, i)) pt_special_walk(v, P.sp, P.occ, P.flags, i);
 }
 
 // flags -> offsets, pass 1: number of starts per workgroup of PT_PER_BLOCK bytes
@@ -214,7 +213,7 @@ struct PretokOut {
 };
 
 // Runs all passes on `text` (device).  chunk_off: device array of n_chunks chunk starts.  cls: device class table.
-// Scratch (meta, flags, occ) is allocated and released here; out->off is the caller's to free.
+// Scratch (meta, flags) is allocated and released here; out->off is the caller's to free.
 inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n, const unsigned long long *chunk_off, uint32_t n_chunks,
                        const uint8_t *cls, const PtSpecials &sp_dev, PretokOut *out) {
     out->off = nullptr;
@@ -226,7 +225,7 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
         YB_RET(hipStreamSynchronize(s));
         return 0;
     }
-    uint8_t *meta = nullptr, *flags = nullptr, *occ = nullptr;
+    uint8_t *meta = nullptr, *flags = nullptr;
     unsigned long long *err = nullptr, *sums = nullptr, *bases = nullptr;
     const unsigned long long nb = (n + PT_PER_BLOCK - 1) / PT_PER_BLOCK;
     int rc = -1;
@@ -234,10 +233,9 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
         if (hipMalloc((void **)&meta, n) != hipSuccess || hipMalloc((void **)&flags, n + 8) != hipSuccess) break;
         if (hipMalloc((void **)&err, 8) != hipSuccess || hipMalloc((void **)&sums, nb * 8) != hipSuccess) break;
         if (hipMalloc((void **)&bases, (nb + 1) * 8) != hipSuccess) break;
-        if (sp_dev.n && hipMalloc((void **)&occ, n) != hipSuccess) break;
         if (hipMemsetAsync(meta, 0, n, s) != hipSuccess || hipMemsetAsync(err, 0xff, 8, s) != hipSuccess) break;
         const uint32_t grid = (uint32_t)std::min<unsigned long long>((n + BLOCK - 1) / BLOCK, 1u << 20);
-        PretokParams P{text, meta, flags, occ, n, cls, err, sp_dev};
+        PretokParams P{text, meta, flags, n, cls, err, sp_dev};
         hipLaunchKernelGGL(k_pt_mark_chunks, dim3((n_chunks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, meta, chunk_off, n_chunks, n);
         const uint32_t wgrid = (uint32_t)std::min<unsigned long long>((n + PT_WIN - 1) / PT_WIN, 1u << 20);
         hipLaunchKernelGGL(k_pt_fused, dim3(wgrid), dim3(BLOCK), 0, s, P);
@@ -248,10 +246,7 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
             rc = 0;
             break;
         }
-        if (sp_dev.n) {
-            hipLaunchKernelGGL(k_pt_special_find, dim3(grid), dim3(BLOCK), 0, s, P);
-            hipLaunchKernelGGL(k_pt_special_resolve, dim3(grid), dim3(BLOCK), 0, s, P);
-        }
+        if (sp_dev.n) hipLaunchKernelGGL(k_pt_special, dim3(grid), dim3(BLOCK), 0, s, P);
         hipLaunchKernelGGL(k_pt_count, dim3((uint32_t)nb), dim3(BLOCK), 0, s, flags, n, sums);
         if (hipGetLastError() != hipSuccess) break;
         if (exclusive_scan<unsigned long long>(s, sums, nb, bases, nb + 1) != 0) break;
@@ -266,7 +261,6 @@ inline int pretokenize(hipStream_t s, const uint8_t *text, unsigned long long n,
     } while (false);
     (void)hipFree(meta);
     (void)hipFree(flags);
-    (void)hipFree(occ);
     (void)hipFree(err);
     (void)hipFree(sums);
     (void)hipFree(bases);
