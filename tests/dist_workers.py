@@ -176,6 +176,10 @@ def gpu_sharded(rank, world, dist, scenario):
         freq, merges = None, 400
         opts.update({"delta_cap": 4, "delta_table_log2": 6, "table_min_log2": 10, "check_interval": 5,
                      "retile_pct": 95, "retile_min_tiles": 8})
+    elif scenario == "synthetic_medium":  # big enough for the split forms, signatures, candidate argmax, a retile
+        flat, off = synth.generate(synth.SynthSpec(24 << 20, 100_000, 13, bytes(range(256)), False))
+        freq, merges = None, 2000
+        opts = {}
     elif scenario == "long_words":
         words = [b" " * 900, b"ab" * 700, b"xyz" * 50, b"abcabc", b"  ", b"aaa"] * 3 + [b"hello world"] * 5
         flat, off = helpers.flatten(words)
