@@ -255,7 +255,7 @@ def main() -> None:
                                   "equals_generator_words": bool(nw_pt == tw), "cpu_baseline": cpu_pt,
                                   "note": "yabpe_pretokenize (UTF-8 validation + GPT-2 split + special tokens -> word offsets in HBM), "
                                           "wall time incl. scratch allocation, best of 3; not part of `value`"}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N=1 item)
         cb, (cflat, coff, cmg) = cpu_baseline(gen, pb, po, n_words, n_bytes, args.merges, args.cpu_sample_mib << 20, specials)
         out["cpu_baseline"] = cb
     if runner is not None:
