@@ -309,7 +309,7 @@ int cand_attach(yabpe_ctx *c) {
     c->use_cand = false;
     if (!optv(c, "cand_argmax", 1)) return 0;
     PairTable &t = c->table;
-    const uint64_t words = ((uint64_t)t.cap + 31) / 32 + 1;
+    const uint64_t words = touched_words(t.cap);
     if (!t.touched) {
         TRY(dmalloc(c, &t.touched, words));
         TRY(dmalloc(c, &t.incand, words));
@@ -331,7 +331,7 @@ int cand_attach(yabpe_ctx *c) {
 int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->use_cand = false;
     if (!optv(c, "cand_argmax", 1) || !c->table.touched || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
-    const uint64_t words = ((uint64_t)c->table.cap + 31) / 32 + 1;
+    const uint64_t words = touched_words(c->table.cap);
     HIPCHK(c, hipMemsetAsync(c->table.touched, 0, words * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
     CandState h{best_count - best_count / 5, 0u, 0u, 0u, 0u};

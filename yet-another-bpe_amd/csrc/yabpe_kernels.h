@@ -74,6 +74,8 @@ struct PairTable {
     uint32_t *touched;           // optional bitmap: slots that received a positive update since k_argmax_cand last looked
     uint32_t *incand;            // optional bitmap: slots already in the candidate list
 };
+// words of the `touched` / `incand` bitmaps of a table of `cap` slots: a multiple of 4 (they are read as uint4)
+YB_HD uint32_t touched_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
 __device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
     return (uint32_t)(((unsigned long long)hash32(key) * t.cap) >> 32);
@@ -2286,20 +2288,28 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
             const Best b{(unsigned long long)cn, (rl << 16) | rr, e.y, e.x, 0u};
             if (best_gt(b, best)) best = b;
         }
-        const uint32_t words = (P.table.cap + 31) >> 5;
-        for (uint32_t w = tid; w < words; w += nth) {
-            uint32_t bits = P.table.touched[w];
-            if (!bits) continue;
-            P.table.touched[w] = 0u;
-            while (bits) {
-                const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
-                bits &= bits - 1;
-                cand_eval(P, s, best);
-                if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
-                    const uint32_t bit = 1u << (s & 31);
-                    if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
-                        const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-                        if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the bitmap is read four words at a time (it is allocated in multiples of 16 B): a thread's loop is a chain of
+        // round trips -- the branch on each word keeps the next load from being issued early -- and this quarters it
+        const uint32_t words4 = touched_words(P.table.cap) >> 2;
+        uint4 *t4 = reinterpret_cast<uint4 *>(P.table.touched);
+        for (uint32_t w4 = tid; w4 < words4; w4 += nth) {
+            const uint4 b4 = t4[w4];
+            if (!(b4.x | b4.y | b4.z | b4.w)) continue;
+            t4[w4] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t bits = q == 0 ? b4.x : q == 1 ? b4.y : q == 2 ? b4.z : b4.w;
+                const uint32_t w = (w4 << 2) + (uint32_t)q;
+                while (bits) {
+                    const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
+                    bits &= bits - 1;
+                    cand_eval(P, s, best);
+                    if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
+                        const uint32_t bit = 1u << (s & 31);
+                        if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
+                            const uint32_t idx = atomicAdd(&P.cs->n, 1u);
+                            if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
