@@ -54,6 +54,7 @@ with _native.Context() as g:
                       % (ss[1] / ss[0], ss[2] / ss[0], ss[3] / ss[0], ss[4] / ss[0], ss[0]))
             sp = (ctypes.c_uint64 * 16)(); _native.lib().yabpe_debug_sel_profile(sp); sp = [int(v) for v in sp]
             rel = lambda i: (sp[i] - sp[0]) / 100.0
+            print("  k_argmax_cand wg0: state loaded %.2f | list evaluated %.2f | bitmap evaluated %.2f us" % (rel(10), rel(11), rel(12)))
             print("  k_argmax_cand+select (last launch): wg0 partial stored %.2f | last ticket %.2f | loads in %.2f | winner decided %.2f | len/off %.2f | bytes+hash %.2f | probe %.2f | end %.2f us"
                   % (rel(9), rel(1), rel(2), rel(3), rel(4), rel(5), rel(6), rel(7)))
             for k in (1, 2, 3, 4, 7):

@@ -2267,9 +2267,13 @@ __device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best 
     if (best_gt(e, best)) best = e;
 }
 
+constexpr int ARGMAX_SLOTS = 2048; // touched slots a workgroup of k_argmax_cand collects before dealing them out
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     __shared__ Best s_b[WPB];
-    __shared__ uint32_t s_last;
+    __shared__ uint32_t s_last, s_nslots;
+    __shared__ uint32_t s_slots[ARGMAX_SLOTS];
+    if (threadIdx.x == 0) s_nslots = 0;
+    __syncthreads();
 #ifdef YB_PROFILE_SCAN
     if (blockIdx.x == 0) YB_SEL_STAMP(0);
     if (blockIdx.x == 0) YB_SEL_STAMP(8);
@@ -2277,6 +2281,9 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     const uint32_t stop = P.st->done | P.st->halt; // (these three loads do not depend on each other: one round trip)
     const unsigned long long T = P.cs->T;
     const uint32_t n0 = min(P.cs->n_seen, CAND_CAP); // (not n: see CandState)
+#ifdef YB_PROFILE_SCAN
+    if (blockIdx.x == 0 && (stop | (uint32_t)T | n0) != 0xdeadbeefu) YB_SEL_STAMP(10);
+#endif
     if (!stop) {
         Best best{0ull, 0u, EMPTY, 0u, 0u};
         const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
@@ -2288,8 +2295,23 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
             const Best b{(unsigned long long)cn, (rl << 16) | rr, e.y, e.x, 0u};
             if (best_gt(b, best)) best = b;
         }
-        // the bitmap is read four words at a time (it is allocated in multiples of 16 B): a thread's loop is a chain of
-        // round trips -- the branch on each word keeps the next load from being issued early -- and this quarters it
+#ifdef YB_PROFILE_SCAN
+        if (blockIdx.x == 0 && best.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11);
+#endif
+        // The slots whose count went up.  The bitmap is read four words at a time (it is allocated in multiples of 16 B);
+        // the set bits are first collected in LDS and then dealt to the threads one slot each: evaluating a slot is two
+        // dependent round trips (count + key, then the ranks), and a thread that owned several bits used to walk them one
+        // after the other while its neighbours had none.
+        auto visit = [&](uint32_t s) {
+            cand_eval(P, s, best);
+            if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
+                const uint32_t bit = 1u << (s & 31);
+                if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
+                    const uint32_t idx = atomicAdd(&P.cs->n, 1u);
+                    if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
         const uint32_t words4 = touched_words(P.table.cap) >> 2;
         uint4 *t4 = reinterpret_cast<uint4 *>(P.table.touched);
         for (uint32_t w4 = tid; w4 < words4; w4 += nth) {
@@ -2303,17 +2325,16 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
                 while (bits) {
                     const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
                     bits &= bits - 1;
-                    cand_eval(P, s, best);
-                    if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
-                        const uint32_t bit = 1u << (s & 31);
-                        if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
-                            const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-                            if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+                    const uint32_t k = atomicAdd(&s_nslots, 1u);
+                    if (k < (uint32_t)ARGMAX_SLOTS) s_slots[k] = s; else visit(s); // (list full: this thread does it)
                 }
             }
         }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < min(s_nslots, (uint32_t)ARGMAX_SLOTS); k += BLOCK) visit(s_slots[k]);
+#ifdef YB_PROFILE_SCAN
+        if (blockIdx.x == 0 && best.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(12);
+#endif
         best = best_wave_reduce(best);
         const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
         if (lane == 0) s_b[wib] = best;
