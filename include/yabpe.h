@@ -50,8 +50,8 @@ void yabpe_destroy(yabpe_ctx *ctx);
 /* Message of the last error on this context (ctx == NULL: of the last failed yabpe_create). Never NULL. */
 const char *yabpe_last_error(const yabpe_ctx *ctx);
 
-/* Tunables by name (see DESIGN.md "Tunables"): "check_interval", "recount_every", "retile_frac",
-   "apply_blocks", "event_sample", "table_min_log2", "verify" ... */
+/* Tunables by name (see DESIGN.md "Tunables"): "check_interval", "retile_pct", "apply_blocks", "event_sample",
+   "table_min_log2", "skip_index", "cand_argmax", "verify" ... */
 int yabpe_set_option(yabpe_ctx *ctx, const char *name, int64_t value);
 
 /* Base vocabulary ------------------------------------------------------------------------------------
@@ -113,7 +113,7 @@ typedef struct yabpe_stats_t {
     /* skip index: launches of k_scan_skip and the tiles they actually read (the rest was skipped by signature) */
     uint64_t scan_skip_launches;
     uint64_t scan_skip_tiles_read;
-    /* candidate argmax: list rebuilds (one per check interval) and merges that fell back to the full table scan */
+    /* candidate argmax: rebuilds of the candidate list (scans of the table) and batches that fell back to the full table scan */
     uint64_t cand_rebuilds;
     uint64_t cand_rescans;
 } yabpe_stats_t;
