@@ -1590,7 +1590,7 @@ struct ApplySkipParams {
 };
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK, 6) void k_apply_skip(ApplySkipParams Q) {
+__global__ __launch_bounds__(BLOCK) void k_apply_skip(ApplySkipParams Q) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     __shared__ uint32_t s_keys[AGG_N];
     __shared__ AggV s_vals[AGG_N];
