@@ -59,7 +59,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--target-mib", type=int, default=1024)
     ap.add_argument("--merges", type=int, default=32000)
     ap.add_argument("--event-sample", type=int, default=16, help="time every Nth apply launch with HIP events (0 = off)")
