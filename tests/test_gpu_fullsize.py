@@ -1,0 +1,60 @@
+"""GPU, BASELINE.json's full size (configs[2]): the 1 GiB synthetic byte corpus, 32,000 merges, against the pin the CPU
+oracle produced for exactly this job (tests/golden/g7_config3_meta.json, made by tests/golden/make_golden_config3.py),
+plus the size-independent properties of the path: the best count never increases, the incrementally maintained pair
+table equals a recount of the final stream, tokens only disappear through recorded merge sites, flat and pooled layouts
+and a second run give the same merges."""
+from __future__ import annotations
+
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+SP = ["<|endoftext|>"]
+
+
+def test_config3_one_gib_32k_merges(golden_dir):
+    from yet_another_bpe import _native, synth
+
+    meta = json.loads((golden_dir / "g7_config3_meta.json").read_text())
+    spec = synth.SynthSpec.config3(1024 << 20)
+    base = helpers.base_tokens(SP)
+    with _native.Context() as gen:
+        pb, po, nw, nb = gen.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
+        assert (nb, nw) == (meta["corpus_bytes"], meta["n_words"])
+        assert hashlib.sha256(gen.d2h(pb, nb).tobytes()).hexdigest() == meta["corpus_sha256"]  # same corpus as the oracle's
+        triples = []
+        for dedup in (False, True, False):
+            with _native.Context() as ctx:
+                ctx.set_vocab(base)
+                ctx.load_words_ptr(pb, po, nw, dedup=dedup)
+                left, right, merged, count = ctx.train(32000, 1)
+                st = ctx.stats()
+                assert ctx.verify_table() == 0                                  # incremental table == recount of the stream
+                sites, _live = ctx.iter_log()
+                assert len(left) == meta["n_merges"] and st["n_long_words"] == 0
+                assert int(count[0]) == meta["first_count"] and int(count[-1]) == meta["last_count"]
+                assert bool(np.all(count[:-1] >= count[1:]))                    # best count never increases
+                if not dedup:                                                   # flat: every site removes exactly one token
+                    assert st["tokens_initial"] - st["tokens_now"] == int(np.asarray(sites, dtype=np.uint64).sum())
+                else:
+                    assert st["n_words"] == meta["unique_words"]
+                h = hashlib.sha256(left.astype(np.uint32).tobytes() + right.astype(np.uint32).tobytes() + merged.astype(np.uint32).tobytes()).hexdigest()
+                triples.append(h)
+                if len(triples) == 1:  # the byte-level merges list, as the golden files serialise it, at several prefixes
+                    toks = list(base)
+                    merges = []
+                    for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+                        merges.append((toks[l], toks[r]))
+                        if m == len(toks):
+                            toks.append(toks[l] + toks[r])
+                    lines = oracle.merges_hex(merges).splitlines(keepends=True)
+                    for k, digest in meta["merges_sha256"].items():
+                        assert hashlib.sha256("".join(lines[: int(k)]).encode()).hexdigest() == digest, f"first {k} merges differ from the oracle"
+                    assert len(toks) == meta["vocab_size"]
+        assert triples[0] == triples[1] == triples[2] == meta["id_triples_sha256"]  # layouts and repeated runs agree with the oracle
