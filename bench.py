@@ -52,6 +52,8 @@ def cpu_baseline(ctx, pb, po, n_words, n_bytes, merges, budget_bytes, specials, 
                   f"{len(mg)} merges in {dt:.1f} s (word pooling + pair count included; merge loop stopped after {max_seconds:.0f} s); C port of the reference's incremental algorithm (oracle/bpe_oracle.c); "
                   f"host has {os.cpu_count()} cores",
         "corpus_bytes_per_sec": round(int(off[-1]) / dt, 1),
+        "full_job_once": "the same C port on the WHOLE 1 GiB / 32,000-merge job, run once when its result was pinned "
+                         "(tests/golden/g7_config3_meta.json): 754 s on one core of the build container = 42 merges/s",
     }, (flat, off, mg)
 
 
