@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define YABPE_ABI_VERSION 1
+#define YABPE_ABI_VERSION 2
 
 enum {
     YABPE_OK = 0,
@@ -116,6 +116,8 @@ typedef struct yabpe_stats_t {
     /* candidate argmax: rebuilds of the candidate list (scans of the table) and batches that fell back to the full table scan */
     uint64_t cand_rebuilds;
     uint64_t cand_rescans;
+    /* fused per-merge launches: apply of merge i + selection of merge i+1 in one kernel (the production form) */
+    uint64_t fused_launches;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

@@ -37,7 +37,7 @@ def test_header_symbols_are_exported(lib_path):
     for n in names:
         assert hasattr(lib, n), n
     lib.yabpe_abi_version.restype = ctypes.c_int
-    assert lib.yabpe_abi_version() == 1
+    assert lib.yabpe_abi_version() == 2
 
 
 def test_no_device_fails_loudly(lib_path):

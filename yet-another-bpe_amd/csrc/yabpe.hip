@@ -162,10 +162,15 @@ struct yabpe_ctx {
     CandState *cand_state = nullptr;
     uint32_t cand_built_at = 0;      // merge index (of this yabpe_train call) at which cand[] was last rebuilt
     unsigned long long cand_best_at_build = 0;
-    uint32_t *sel_ticket = nullptr;  // k_argmax_cand: finished-workgroup counter (the last one selects; resets itself)
-    uint2 *cand = nullptr;
+    uint32_t *sel_ticket = nullptr;  // finished-workgroup counters (TICKET_WORDS; the last workgroup selects; they reset themselves)
+    unsigned long long *cand = nullptr;
     bool use_cand = false;
     uint64_t cand_rebuilds = 0, cand_rescans = 0;
+    double cand_margin = 0.2;        // T = best count x (1 - margin); adapted so that the list stays short
+    uint32_t cand_n_at_build = 0;
+    // fused per-merge launch: the apply kernel of merge i ends with the selection of merge i + 1
+    bool pending = false;            // a merge has been selected (recorded) and not applied yet
+    uint64_t fused_launches = 0;
     // multi-GPU
     int rank = 0, n_ranks = 1;
     bool multi = false;  // exchange path active (n_ranks > 1, or a 1-rank communicator forced for testing)
@@ -285,11 +290,13 @@ int state_push(yabpe_ctx *c) {
 void table_free(PairTable &t) {
     dfree(t.keys);
     dfree(t.cnt);
-    dfree(t.touched);
     dfree(t.incand);
     t.keys = nullptr;
     t.cnt = nullptr;
-    t.touched = t.incand = nullptr;
+    t.incand = nullptr;
+    t.cand_cs = nullptr;
+    t.cand_list = nullptr;
+    t.cand_T = 0;
 }
 
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
@@ -298,27 +305,28 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.cap = (uint32_t)cap;
     t.max_probe = (uint32_t)std::min<uint64_t>(cap, 2048);
     t.entries = entries_ctr;
-    t.touched = t.incand = nullptr;  // attached to the main table only, once it is built (cand_attach)
+    t.incand = nullptr;  // the candidate list is attached to the main table only, once it is built (cand_attach / cand_rebuild)
+    t.cand_cs = nullptr;
+    t.cand_list = nullptr;
+    t.cand_T = 0;
     HIPCHK(c, hipMemsetAsync(t.keys, 0xFF, cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(unsigned long long), c->stream));
     return 0;
 }
 
-// bitmaps of the candidate argmax for the main table (cleared; the candidate list is rebuilt by the caller's next check)
+// bitmap of the candidate argmax for the main table (cleared; the candidate list is rebuilt by the caller's next check)
 int cand_attach(yabpe_ctx *c) {
     c->use_cand = false;
-    if (!optv(c, "cand_argmax", 1)) return 0;
     PairTable &t = c->table;
-    const uint64_t words = touched_words(t.cap);
-    if (!t.touched) {
-        TRY(dmalloc(c, &t.touched, words));
-        TRY(dmalloc(c, &t.incand, words));
-    }
-    HIPCHK(c, hipMemsetAsync(t.touched, 0, words * 4, c->stream));
+    t.cand_cs = nullptr;
+    t.cand_list = nullptr;
+    if (!optv(c, "cand_argmax", 1)) return 0;
+    const uint64_t words = incand_words(t.cap);
+    if (!t.incand) TRY(dmalloc(c, &t.incand, words));
     HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
     if (!c->sel_ticket) {
-        TRY(dmalloc(c, &c->sel_ticket, 1));
-        HIPCHK(c, hipMemsetAsync(c->sel_ticket, 0, 4, c->stream));
+        TRY(dmalloc(c, &c->sel_ticket, TICKET_WORDS));
+        HIPCHK(c, hipMemsetAsync(c->sel_ticket, 0, TICKET_WORDS * 4, c->stream));
     }
     if (!c->cand_state) {
         TRY(dmalloc(c, &c->cand_state, 1));
@@ -327,27 +335,46 @@ int cand_attach(yabpe_ctx *c) {
     return 0;
 }
 
-// cand[] = every slot with count >= 0.8 x best_count; enables the candidate argmax for the next batch
+// list = every slot with count >= T, T = best_count x (1 - margin); enables the candidate argmax from here on.  While the
+// list is attached to c->table, every kernel that raises a count appends to it (cand_note), so it stays exact for as long
+// as the maximum stays >= T.  The margin adapts: the fused selection is ONE workgroup reading the whole list.
 int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->use_cand = false;
-    if (!optv(c, "cand_argmax", 1) || !c->table.touched || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
-    const uint64_t words = touched_words(c->table.cap);
-    HIPCHK(c, hipMemsetAsync(c->table.touched, 0, words * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
-    CandState h{best_count - best_count / 5, 0u, 0u, 0u, 0u};
-    HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    CandParams P{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, nullptr, SelectParams{}};
+    c->table.cand_cs = nullptr;
+    c->table.cand_list = nullptr;
+    if (!optv(c, "cand_argmax", 1) || !c->table.incand || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
+    const uint64_t words = incand_words(c->table.cap);
+    const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 1536));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
-    hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&h, c->cand_state, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->cand_rebuilds++;
+    CandState h{};
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        unsigned long long margin = (unsigned long long)((double)best_count * c->cand_margin);
+        if (margin < 1) margin = 1;
+        HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
+        h = CandState{best_count - std::min(margin, best_count - 1), 0u, 0u, 0u, 0u};
+        HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        PairTable t = c->table;
+        t.cand_list = c->cand;
+        CandParams P{t, c->tt.rank, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
+        hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&h, c->cand_state, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cand_rebuilds++;
+        if ((h.overflow || h.n > target) && margin > 1) { // too many pairs that close to the top: halve the margin, again
+            c->cand_margin *= 0.5;
+            continue;
+        }
+        break;
+    }
+    if (h.n < target / 8) c->cand_margin = std::min(0.2, c->cand_margin * 2.0); // room to spare: rebuild less often next time
     c->use_cand = !h.overflow && h.n < CAND_CAP / 2;
-    // the list is complete: publish its length (k_argmax_cand reads n_seen, never the moving n)
-    const uint32_t seen = std::min<uint32_t>(h.n, CAND_CAP);
-    HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->cand_state) + offsetof(CandState, n_seen), &seen, 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cand_n_at_build = h.n;
+    if (c->use_cand) {
+        c->table.cand_cs = c->cand_state;
+        c->table.cand_list = c->cand;
+        c->table.cand_T = h.T;
+    }
     return 0;
 }
 
@@ -1012,6 +1039,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.scan_actual_bytes_sampled = 0;
     c->scan_skip_launches = 0;
     c->cand_rebuilds = c->cand_rescans = 0;
+    c->fused_launches = 0;
     if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
@@ -1037,17 +1065,23 @@ static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
     return 0;
 }
 
-static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev) {
-    uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64) : c->n_partials;
-    SelectParams S{c->partials, n_part, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
-                   c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
-                   c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(c->blk_used, 1u),
-                   c->use_cand ? c->cand_state : nullptr};
-    c->blk_used = 0;  // the selection folds and clears them; what follows counts this merge's grids
+static SelectParams select_params(yabpe_ctx *c, uint32_t rec_base, uint32_t n_part, uint32_t n_blk) {
+    return SelectParams{c->partials, n_part, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
+                        c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
+                        c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(n_blk, 1u),
+                        c->use_cand ? c->cand_state : nullptr};
+}
+
+// The selection as launches of its own (trainer.py:241-251, 296-300): exact argmax over the candidate list, or over the
+// whole table when there is no list, then stop rules and merged-token creation.
+static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
+    const uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64) : c->n_partials;
+    const SelectParams S = select_params(c, rec_base, n_part, c->blk_used);
+    c->blk_used = 0;  // the selection folds and clears them; what follows counts the next merge's grids
     bool selected = false;
-    if (c->use_cand) {  // exact argmax over the candidate list + the slots updated since (no table scan)
+    if (c->use_cand) {
         const bool fuse = optv(c, "fuse_select", 1) != 0;
-        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, c->cand, fuse ? c->sel_ticket : nullptr, S};
+        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;
     } else {
@@ -1055,11 +1089,25 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
     }
     if (!selected) hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Can the apply launch of the merge that is selected now end with the selection of the next one?
+static bool can_fuse(yabpe_ctx *c) {
+    if (!c->use_cand || c->multi || !optv(c, "fused", 1) || !c->n_tiles) return false;
+    if (!c->split_mode) return true;  // k_apply
+    return c->sig && c->sig_valid && !optv(c, "fuse_skip", 0) && c->dense_mode && optv(c, "full_skip", 1);  // k_scan_skip, FULL form
+}
+
+// Applies the merge in DevState to the token stream and the pair table (trainer.py:254-294).  fuse: the launch that
+// finishes the apply also selects the next merge (its last workgroup; see fused_select_tail) -- one launch per merge.
+static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev, bool fuse) {
     RankParams R{c->tt, c->st};
     const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
     // lexrank maintenance rides on the k_scan_skip launch when that form is used (one dependent launch fewer)
     // ... and on the fused k_apply launch
-    const bool rank_rides = c->n_tiles && optv(c, "rank_rides", 1) &&
+    const bool rank_rides = c->n_tiles && (fuse || optv(c, "rank_rides", 1)) &&
                             (c->split_mode ? (c->sig && c->sig_valid && !optv(c, "fuse_skip", 0)) : true);
     if (!rank_rides) hipLaunchKernelGGL(k_rank_update, dim3(rank_blocks), dim3(BLOCK), 0, c->stream, R);
     const PairTable out_table = c->multi ? c->delta : c->table;
@@ -1067,15 +1115,29 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         ev->split = c->split_mode;
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
+    if (fuse && c->n_long) {  // the long words first: the fused launch must be the last one to touch the table
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
+        hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+    }
+    // the fused selection folds the per-workgroup counters of THIS launch too: it must know the larger grid
+    auto fuse_params = [&](uint32_t grid_now) {
+        FuseParams F{};
+        if (fuse) {
+            F.ticket = c->sel_ticket;
+            F.sel = select_params(c, rec_base, 0u, std::max(c->blk_used, grid_now));
+        }
+        return F;
+    };
     if (c->n_tiles) {
         ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats,
                       c->split_mode ? c->sig : nullptr, c->sig_stride};  // signatures are maintained in the split form only
         if (!c->split_mode) {
+            const FuseParams F = fuse_params(apply_grid);
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
-                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R);
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
             else
-                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R);
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
             // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
@@ -1112,7 +1174,8 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
                 seg = chunk * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
-                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, R};
+                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, R, fuse_params(full ? scan_grid : 0u)};
+                if (!full) SQ.F.ticket = nullptr;  // (can_fuse() never asks for this form)
                 c->blk_used = std::max(c->blk_used, scan_grid);
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
                 const bool inl = !c->weighted && optv(c, "inline_single", 1);
@@ -1155,7 +1218,11 @@ static int launch_iteration(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upp
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
-    if (c->n_long) {
+    if (fuse) {
+        c->blk_used = 0;  // folded by the selection at the end of that launch
+        c->fused_launches++;
+    }
+    if (!fuse && c->n_long) {
         LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
         hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
     }
@@ -1229,7 +1296,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     uint32_t i = 0;
     bool finished = false;
     bool skip_cand_once = false;
+    unsigned long long prev_best = 0;
     c->use_cand = false;
+    c->pending = false;
     while (!finished) {
         // (re)size the argmax grid to the table
         uint32_t want_partials = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
@@ -1263,15 +1332,19 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // the argmax itself), so it is rebuilt -- a scan of the whole table -- only now and then: when there is none
             // (start, table rebuilt or grown, fallback), and every `cand_rebuild_every` merges to keep it short.
             const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "cand_rebuild_every", 512));
-            // ... and before the maximum gets close to T (0.8 x the best count at build time): a fallback costs the rest
-            // of a batch.  Early in a run the best count falls by more than that per batch, so the list is rebuilt every
-            // batch there; late in the run hardly ever.
-            const bool near_T = h->best_count * 100 < c->cand_best_at_build * 92;  // T = 0.80, margin up to 0.92
-            if (!c->use_cand || i - c->cand_built_at >= every || near_T) {
+            // ... and before the maximum can reach T within the next two batches at the pace of the last one: a fallback
+            // costs the rest of a batch.  Early in a run the best count falls fast, so the list is rebuilt every batch
+            // there; late in the run hardly ever.  A list that has grown long (appended slots) is rebuilt too: the fused
+            // selection is one workgroup reading all of it.
+            const unsigned long long drop = prev_best > h->best_count ? prev_best - h->best_count : 0;
+            const bool near_T = h->best_count < c->table.cand_T + 2 * drop + 1;
+            const bool long_list = h->cand_n > 3u * (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 1536));
+            if (!c->use_cand || i - c->cand_built_at >= every || near_T || long_list) {
                 TRY(cand_rebuild(c, h->best_count));
                 c->cand_built_at = i;
                 c->cand_best_at_build = h->best_count;
             }
+            prev_best = h->best_count;
         }
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
@@ -1286,24 +1359,40 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             }
         }
         uint32_t batch_end = std::min(num_merges, i + ((i == 0 && !c->split_mode) ? std::min<uint32_t>(check, 8) : check));
-        for (; i < batch_end; ++i) {
-            EventPair *ev = nullptr;
-            if (ev_sample && (i % ev_sample) == 0) {
-                if (ev_next == c->events.size()) {
-                    EventPair n{};
-                    HIPCHK(c, hipEventCreate(&n.e0));
-                    HIPCHK(c, hipEventCreate(&n.e1));
-                    HIPCHK(c, hipEventCreate(&n.e2));
-                    c->events.push_back(n);
-                }
-                c->events[ev_next].iter_rel = i;
-                ev = &c->events[ev_next++];
+        auto sample = [&](uint32_t iter_rel) -> EventPair * {
+            if (!ev_sample || (iter_rel % ev_sample) != 0) return nullptr;
+            if (ev_next == c->events.size()) {
+                EventPair n{};
+                if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess || hipEventCreate(&n.e2) != hipSuccess) return nullptr;
+                c->events.push_back(n);
             }
-            TRY(launch_iteration(c, rec_base, tokens_start + i + 1, apply_grid, ev));
+            c->events[ev_next].iter_rel = iter_rel;
+            return &c->events[ev_next++];
+        };
+        // i = merges whose selection has been launched.  Fused form: one launch applies merge i - 1 and selects merge i;
+        // otherwise a merge is a selection launch followed by its apply launch(es).
+        const bool fuse = can_fuse(c);
+        if (c->pending && (!fuse || i >= num_merges)) {  // leave the fused form: the selected merge is applied on its own
+            TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i - 1), false));
+            c->pending = false;
+        }
+        if (fuse && !c->pending && i < batch_end) {  // enter it: a selection on its own
+            TRY(launch_select(c, rec_base));
+            c->pending = true;
+            ++i;
+        }
+        for (; i < batch_end; ++i) {
+            if (fuse) {
+                TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i - 1), true));
+            } else {
+                TRY(launch_select(c, rec_base));
+                TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i), false));
+            }
         }
         TRY(fold_stats(c));
         TRY(state_pull(c));
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
+        if (h->done || h->halt) c->pending = false;          // the last selection of the batch did not select
         if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
             unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
             TRY(comm_max(c, sig, &mx));
@@ -1344,7 +1433,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
             return fail(c, YABPE_E_CAPACITY, "%s after %u merges", why, h->iter - rec_base);
         }
-        if (h->done || i >= num_merges) {
+        if (h->done || (i >= num_merges && !c->pending)) {
             finished = true;
             break;
         }
@@ -1373,9 +1462,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     if (n) {
         HIPCHK(c, hipMemcpy(c->log_sites.data(), c->rec_sites, (size_t)n * 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(c->log_live.data(), c->rec_live, (size_t)n * 8, hipMemcpyDeviceToHost));
-        c->log_sites[n - 1] = h->sites;
+        c->log_sites[n - 1] += h->sites;  // (already closed by the selection when the last launch was a fused one: then h->sites is 0)
     }
-    const uint64_t tokens_at_start = h->tokens_now + [&] { uint64_t s = 0; for (uint32_t k = 0; k + 1 < n; ++k) s += c->log_sites[k]; return s; }();
+    const uint64_t tokens_at_start = h->tokens_now - h->sites + [&] { uint64_t s = 0; for (uint32_t k = 0; k < n; ++k) s += c->log_sites[k]; return s; }();
     h->tokens_now -= h->sites;
     h->sites = 0;
     TRY(state_push(c));
@@ -1462,6 +1551,7 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.table_entries = c->st_host->table_entries;
     c->stats.cand_rebuilds = c->cand_rebuilds;
     c->stats.cand_rescans = c->cand_rescans;
+    c->stats.fused_launches = c->fused_launches;
     c->stats.scan_skip_launches = c->scan_skip_launches;
     c->stats.scan_skip_tiles_read = 0;
     if (c->blk_read) {
@@ -1549,6 +1639,14 @@ int yabpe_debug_sel_profile(unsigned long long out[16]) {
 }
 int yabpe_debug_ss_profile(unsigned long long out[8]) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_ss_prof), 64) == hipSuccess ? 0 : -1;
+}
+int yabpe_debug_launch_profile(unsigned long long *out, int reset) { // 65536 x 4 u64
+    if (reset) {
+        std::vector<unsigned long long> z(65536 * 4, 0ull);
+        for (size_t i = 0; i < 65536; ++i) z[i * 4] = ~0ull;
+        return hipMemcpyToSymbol(HIP_SYMBOL(yb::g_launch_prof), z.data(), z.size() * 8) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_launch_prof), (size_t)65536 * 32) == hipSuccess ? 0 : -1;
 }
 int yabpe_debug_scan_profile(unsigned long long *out, uint32_t n_blocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_scan_prof), (size_t)std::min<uint32_t>(n_blocks, yb::MAX_LISTS_PROF) * 64) == hipSuccess ? 0 : -1;

@@ -52,7 +52,7 @@ struct DevState {
     uint32_t n_tokens;
     uint32_t pool_used;
     uint32_t num_merges; // iteration limit (trainer.py:238)
-    uint32_t pad0;
+    uint32_t cand_n;     // length of the candidate list when the last selection ran
     unsigned long long min_freq;
     unsigned long long table_entries;
     unsigned long long live_slots; // sum of tile_len
@@ -65,17 +65,29 @@ struct DevState {
     uint32_t pad1;
 };
 
+// candidate argmax state (see k_argmax_cand / fused_select_tail)
+constexpr uint32_t CAND_CAP = 1u << 16; // capacity of the candidate list
+struct CandState {
+    unsigned long long T;
+    uint32_t n, overflow;
+    uint32_t n_seen; // entries of the list that were complete when the last selection ran: what a standalone k_argmax_cand
+    uint32_t pad;    // may read (n itself moves while kernels that update the table run)
+};
+
 struct PairTable {
     uint32_t *keys;
     unsigned long long *cnt;
     uint32_t cap;       // any size >= 2 (not only powers of two: the argmax scan reads every slot, so the table is kept small)
     uint32_t max_probe;
     unsigned long long *entries; // where successful inserts are counted
-    uint32_t *touched;           // optional bitmap: slots that received a positive update since k_argmax_cand last looked
-    uint32_t *incand;            // optional bitmap: slots already in the candidate list
+    // candidate argmax (main table only, else NULL): a count that rises to >= cand_T puts its slot on the candidate list
+    uint32_t *incand;            // bitmap: slots already in the candidate list
+    CandState *cand_cs;          // list length / overflow flag
+    unsigned long long *cand_list; // entries: slot | key << 32
+    unsigned long long cand_T;
 };
-// words of the `touched` / `incand` bitmaps of a table of `cap` slots: a multiple of 4 (they are read as uint4)
-YB_HD uint32_t touched_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
+// words of the `incand` bitmap of a table of `cap` slots
+YB_HD uint32_t incand_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
 __device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
     return (uint32_t)(((unsigned long long)hash32(key) * t.cap) >> 32);
@@ -105,15 +117,6 @@ __device__ __forceinline__ Best best_load_coherent(const Best *p) {
     const unsigned long long c = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return Best{a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)c, 0u};
 }
-
-// candidate argmax state (see k_argmax_cand)
-constexpr uint32_t CAND_CAP = 1u << 16; // capacity of the candidate list
-struct CandState {
-    unsigned long long T;
-    uint32_t n, overflow;
-    uint32_t n_seen; // entries of cand[] that were complete when the last selection ran: what the NEXT argmax may read.
-    uint32_t pad;    // (n itself moves while k_argmax_cand runs -- a workgroup that starts late would otherwise read
-};                   //  slots another workgroup has counted but not stored yet)
 
 // multi-GPU delta exchange records (see k_delta_extract)
 struct DeltaHdr {
@@ -186,6 +189,36 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // ---------------------------------------------------------------- global pair table
+// Values another workgroup of the SAME launch may read (the workgroup that finishes last runs the selection, see
+// fused_select_tail): device-scope stores and loads, coherent across the XCDs' L2s without a cache write-back.
+__device__ __forceinline__ void st_coherent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coherent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_coherent(const unsigned long long *p) { return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p) { return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The count of slot s rose to `now`: once it reaches the threshold of the candidate argmax the slot joins the list (once).
+// Invariant kept between two rebuilds of the list: every slot whose count is >= cand_T is on it.  Counts only go up
+// through the two functions below, so nothing else has to look at the table.
+__device__ __forceinline__ void cand_note(const PairTable &t, uint32_t s, uint32_t key, unsigned long long now) {
+    if (now < t.cand_T || (long long)now <= 0) return;
+    const uint32_t bit = 1u << (s & 31);
+    if (atomicOr(&t.incand[s >> 5], bit) & bit) return;
+    const uint32_t idx = atomicAdd(&t.cand_cs->n, 1u);
+    if (idx < CAND_CAP)
+        st_coherent(&t.cand_list[idx], (unsigned long long)s | ((unsigned long long)key << 32));
+    else
+        st_coherent(&t.cand_cs->overflow, 1u);
+}
+// cnt[s] += d
+__device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t key, long long d) {
+    if (d > 0 && t.cand_list) {
+        const unsigned long long old = atomicAdd(&t.cnt[s], (unsigned long long)d);
+        cand_note(t, s, key, old + (unsigned long long)d);
+    } else {
+        atomicAdd(&t.cnt[s], (unsigned long long)d);
+    }
+}
+
 // `inserted`: optional per-thread counter of new keys; the caller then adds its wave's total to *t.entries itself (one
 // atomic per wave on that one hot address instead of one per new key).
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
@@ -200,10 +233,7 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
             }
         }
         if (k == key) {
-            atomicAdd(&t.cnt[s], (unsigned long long)d);
-            if (d > 0 && t.touched) { // a count went up: the candidate argmax must look at this slot again
-                atomicOr(&t.touched[s >> 5], 1u << (s & 31)); // (no test first: that would be one more round trip)
-            }
+            gt_bump(t, s, key, d);
             return;
         }
         s = pt_next(t, s);
@@ -337,8 +367,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
     for (int q = 0; q < PER; ++q) {
         if (v[q] == 0) continue;
         if (tk[q] == k[q]) {
-            atomicAdd(&t.cnt[home[q]], (unsigned long long)v[q]);
-            if (v[q] > 0 && t.touched) atomicOr(&t.touched[home[q] >> 5], 1u << (home[q] & 31));
+            gt_bump(t, home[q], k[q], v[q]);
         } else {
             gt_add(t, st, k[q], v[q], &ins);
         }
@@ -970,9 +999,9 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
         if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // plain stores; k_select / k_fold_stats sum and clear them
-        P.blk_stats[2 * blockIdx.x] += s_cnt[0];
-        P.blk_stats[2 * blockIdx.x + 1] += s_cnt[1];
+    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // one slot per workgroup, no atomics; the selection sums and clears them
+        st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]); // (it may run in this very launch)
+        st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
     }
     agg_flush(agg, P.out, st);
 }
@@ -1106,7 +1135,7 @@ __device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t 
     if (t < n && t != c) {
         int cmp = tok_cmp(P.tt, t, c);
         if (cmp > 0)
-            P.tt.rank[t] += 1;
+            st_coherent(&P.tt.rank[t], P.tt.rank[t] + 1u); // (read by the selection of the same launch in the fused form)
         else
             less = 1;
     }
@@ -1117,67 +1146,6 @@ __device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t 
 }
 
 __global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) { rank_update_block(P, blockIdx.x); }
-
-// ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
-// (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
-template <bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R) {
-    // workgroups [0, apply_blocks) apply the merge; the rest of the grid does k_rank_update's work in the same launch
-    if (blockIdx.x >= apply_blocks) {
-        rank_update_block(R, blockIdx.x - apply_blocks);
-        return;
-    }
-    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    __shared__ uint32_t s_keys[AGG_N];
-    __shared__ AggV s_vals[AGG_N];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
-    __shared__ unsigned long long s_cnt[2];
-
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    C.mk = yb_memkey(C.a, C.b);
-    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
-    const uint32_t mk = C.mk;
-    agg_init(C.agg);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    WaveLds &W = s_w[wib];
-    wave_lds_init(W, lane);
-    __syncthreads();
-
-    unsigned long long wave_sites = 0; // wave-uniform
-    unsigned long long wave_freed = 0; // slots removed from this wave's tiles
-    const uint32_t stride = apply_blocks * WPB;
-    const uint32_t n_tiles = P.n_tiles;
-    // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
-    // next tile's 2 x 16 B per lane are in flight while the current tile is examined.
-    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
-        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
-        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
-        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
-        TileRegs nxt = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t tile = batch + i * stride;
-            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
-            const TileRegs r = nxt;
-            if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
-            if (len == 0) continue;
-            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
-        }
-    }
-#ifdef YB_PROFILE_SLOW
-    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
-#endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
-}
 
 // ---------------------------------------------------------------- skip index: signatures and the scan that uses them
 struct SigParams {
@@ -1230,247 +1198,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
         }
         __syncthreads();
     }
-}
-
-// Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
-// tile's signature (12 B per tile: length + the 64-bit block that holds the pair's bits); the tiles that may contain
-// the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
-#ifdef YB_PROFILE_SCAN
-__device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];
-#define YB_SCAN_STAMP(i)                                                                       \
-    do {                                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < MAX_LISTS_PROF) g_scan_prof[blockIdx.x * 8 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define YB_SCAN_STAMP(i) do { } while (0)
-#endif
-struct ScanSkipParams {
-    ScanParams S;
-    ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
-    unsigned long long *blk_read; // [scan_blocks] tiles actually read (statistics; plain stores)
-    uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
-    uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
-    uint32_t dense_cap;
-    uint32_t kt;                  // signature tests per thread: a workgroup takes SCAN_CHUNK * kt consecutive tiles at a time
-    RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
-};
-
-// INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
-// (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
-// FULL (sparse merges): the rest is rewritten here too (slow_tile) -- the few tiles involved do not need k_slow's
-// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.  In this form
-// matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
-// already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
-template <bool INLINE, bool FULL, bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 4 workgroups per CU)
-    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    constexpr bool REWRITES = INLINE || FULL;
-    static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
-    __shared__ uint32_t s_n, s_hits, s_nrew;
-    __shared__ uint2 s_list[SCAN_CHUNK * SCAN_KT_MAX];
-    __shared__ uint2 s_rew[REWRITES ? SCAN_CHUNK * SCAN_KT_MAX : 1];
-    __shared__ uint32_t s_keys[REWRITES ? AGG_N : 1];
-    __shared__ AggV s_vals[REWRITES ? AGG_N : 1];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? WPB : 1];
-    __shared__ unsigned long long s_cnt[2];
-    const ScanParams &P = Q.S;
-    DevState *st = P.st;
-    YB_SCAN_STAMP(0);
-    if (blockIdx.x >= Q.scan_blocks) {
-        rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
-        YB_SCAN_STAMP(7);
-        return;
-    }
-    // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
-    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c;
-    if (st_stop) return;
-    const uint32_t n_blocks = Q.scan_blocks;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st_a, st_b, st_c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    const uint32_t a = C.a, b = C.b;
-    const uint32_t mk = yb_memkey(a, b);
-    C.mk = mk;
-    C.self = yb_pairkey(a, b);
-    const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
-    const bool single_ok = INLINE && a != b;
-    const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
-    if (REWRITES) agg_init(C.agg);
-    WaveLds &W = s_w[FULL ? wib : 0];
-    if (FULL) wave_lds_init(W, lane);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        s_n = 0;
-        s_hits = 0;
-        s_nrew = 0;
-    }
-    __syncthreads();
-    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
-    unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
-    const uint32_t kt = Q.kt;
-    const uint32_t chunk = SCAN_CHUNK * kt;
-    const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
-    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
-        // all of this thread's signature words are requested before the first one is looked at
-        uint32_t len[SCAN_KT_MAX];
-        bool maybe[SCAN_KT_MAX];
-#pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
-            const uint32_t t = ch * chunk + j * SCAN_CHUNK + threadIdx.x;
-            len[j] = 0;
-            maybe[j] = false;
-            if (j < kt && t < P.n_tiles) {
-                len[j] = P.tile_len[t];
-                maybe[j] = probe.maybe(t);
-            }
-        }
-        YB_SCAN_STAMP(1);
-#pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
-            if (j >= kt) break; // uniform
-            const bool mb = maybe[j] && len[j] != 0;
-            const unsigned long long m = __ballot(mb);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * SCAN_CHUNK + threadIdx.x, len[j]);
-        }
-        __syncthreads();
-        const uint32_t n = s_n;
-        n_read += n;
-        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched (two in the
-        // FULL form: its rewrite code needs the registers, and a wave rarely has more than three candidates there)
-        constexpr bool DEEP = !FULL;
-        uint32_t j = wib;
-        uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
-        uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
-        uint2 it2 = DEEP && j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
-        TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
-        TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
-        TileRegs q2 = q1;
-        if constexpr (DEEP) q2 = load_tile(P.tiles, it2.x, it2.y, lane);
-        while (j < n) {
-            const uint2 cur = it0;
-            const TileRegs r = q0;
-            it0 = it1;
-            q0 = q1;
-            j += WPB;
-            if constexpr (DEEP) {
-                it1 = it2;
-                q1 = q2;
-                if (j + 2 * WPB < n) {
-                    it2 = s_list[j + 2 * WPB];
-                    q2 = load_tile(P.tiles, it2.x, it2.y, lane);
-                }
-            } else if (j + WPB < n) {
-                it1 = s_list[j + WPB];
-                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
-            }
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            // A rewrite stores to HBM, and on gfx950 stores queue in the same in-order vmcnt as this wave's prefetched
-            // loads: rewriting here would stall the scan behind every store.  Matched tiles are only noted; they are
-            // rewritten after the candidate loop, when no load of this wave is waiting behind the stores.
-            if (FULL) {
-                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
-                const unsigned long long holders = __ballot(mine != 0);
-                const int lane_s = __ffsll((long long)holders) - 1;
-                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
-                bool handled = false;
-                if constexpr (INLINE) {
-                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
-                        handled = true;
-                    }
-                }
-                if (handled) {
-                } else if constexpr (FULL) {
-                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
-                } else if (lane == 0) {
-                    my_work[atomicAdd(&s_hits, 1u)] = cur;
-                }
-            } else if (do_inline) {
-                if (lane == 0) s_rew[atomicAdd(&s_nrew, 1u)] = cur;
-            } else {
-                if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
-            }
-        }
-        __syncthreads();
-        YB_SCAN_STAMP(2);
-        if (!FULL && do_inline) {
-            const uint32_t nr = s_nrew;
-            uint32_t k = wib;
-            uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
-            uint2 w1 = k + WPB < nr ? s_rew[k + WPB] : make_uint2(0u, 0u);
-            TileRegs t0 = load_tile(P.tiles, w0.x, w0.y, lane); // L2 hits: the tile was read a moment ago
-            TileRegs t1 = load_tile(P.tiles, w1.x, w1.y, lane);
-            while (k < nr) {
-                const uint2 cur = w0;
-                const TileRegs r = t0;
-                w0 = w1;
-                t0 = t1;
-                k += WPB;
-                if (k + WPB < nr) {
-                    w1 = s_rew[k + WPB];
-                    t1 = load_tile(P.tiles, w1.x, w1.y, lane);
-                }
-                const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-                const uint32_t na = next_lane(r.va.x, b0);
-                const uint32_t nb = next_lane(r.vb.x, PADPAD);
-                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
-                const unsigned long long holders = __ballot(mine != 0);
-                const int lane_s = __ffsll((long long)holders) - 1;
-                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
-#ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)WPB) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
-#endif
-                bool handled = false;
-                if constexpr (INLINE) {
-                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
-                        handled = true;
-                    }
-                }
-                if (handled) {
-                } else if constexpr (FULL) {
-                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
-                } else if (lane == 0) {
-                    my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
-                }
-#ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)WPB) YB_SCAN_STAMP(6);
-#endif
-            }
-            __syncthreads();
-        }
-        YB_SCAN_STAMP(3);
-        if (threadIdx.x == 0) {
-            s_n = 0;
-            s_nrew = 0;
-        }
-        __syncthreads();
-    }
-    if (!FULL && Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
-        __shared__ uint32_t s_base;
-        __syncthreads();
-        const uint32_t nh = s_hits;
-        if (nh) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&st->work_total, nh);
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < nh; i += BLOCK)
-                if (s_base + i < Q.dense_cap) Q.dense[s_base + i] = my_work[i];
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (!FULL) P.work_cnt[blockIdx.x] = s_hits;
-        if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
-    }
-    YB_SCAN_STAMP(4);
-    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
-    YB_SCAN_STAMP(7);
 }
 
 // ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
@@ -1928,6 +1655,7 @@ __global__ __launch_bounds__(BLOCK) void k_fold_stats(FoldParams P) { fold_block
 
 
 #ifdef YB_PROFILE_SCAN
+__device__ unsigned long long g_launch_prof[65536 * 4]; // per merge: min start, max end of the workgroups, -, selection end
 __device__ unsigned long long g_sel_prof[16];
 #define YB_SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_prof[i] = wall_clock64(); } while (0)
 #else
@@ -1938,7 +1666,9 @@ __device__ unsigned long long g_sel_prof[16];
 // This is a chain of dependent memory round trips on the critical path of every merge, so it is kept short: thread 0
 // works on a register copy of DevState (one load of the whole struct, one store at the end), and everything that does
 // not depend on the winner (DevState, block counters, partials) is requested in the same round.
-__device__ __forceinline__ void select_body(const SelectParams &P) {
+// `best`: this thread's candidate from the caller (the fused form evaluates the candidate list right here, in the workgroup
+// that finished last); partials of other workgroups, if any, are merged in.
+__device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
     __shared__ Best s_b[WPB];
     __shared__ uint32_t s_flag, s_x, s_y, s_pu, s_slot, s_cand, s_eq, s_lo[4];
     __shared__ unsigned long long s_fold[2];
@@ -1951,37 +1681,44 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
     uint32_t cand_over = 0;
     if (tid == 0) {
         d = *st;
+        // fields other workgroups of this launch may have moved (atomics): read them past the caches
+        d.halt_req = ld_coherent(&st->halt_req);
+        d.table_entries = ld_coherent(&st->table_entries);
+        d.delta_entries = ld_coherent(&st->delta_entries);
+        d.sites = ld_coherent(&st->sites);
         if (P.cs) {
             candT = P.cs->T;
-            cand_over = __hip_atomic_load(&P.cs->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // every workgroup of the argmax has finished (kernel boundary, or its ticket): the list is complete up to n
-            P.cs->n_seen = min(__hip_atomic_load(&P.cs->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), CAND_CAP);
+            cand_over = ld_coherent(&P.cs->overflow);
+            d.cand_n = ld_coherent(&P.cs->n);
         }
         s_fold[0] = 0;
         s_fold[1] = 0;
         s_flag = 0;
     }
-    // counters of the last apply pass (plain stores by its workgroups), summed and cleared
+    // counters of the last apply pass (one slot per workgroup), summed and cleared
     unsigned long long fa = 0, ff = 0;
     {
-        ulonglong2 *bs = reinterpret_cast<ulonglong2 *>(P.blk_stats);
-        for (uint32_t i0 = 0; i0 < P.n_blk; i0 += 4 * BLOCK) { // four loads in flight, then the four clears
-            ulonglong2 v[4];
+        unsigned long long *bs = P.blk_stats;
+        for (uint32_t i0 = 0; i0 < P.n_blk; i0 += 4 * BLOCK) { // four slots per thread in flight, then the clears
+            unsigned long long vx[4], vy[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t i = i0 + k * BLOCK + tid;
-                v[k] = i < P.n_blk ? bs[i] : make_ulonglong2(0ull, 0ull);
+                vx[k] = i < P.n_blk ? ld_coherent(&bs[2 * i]) : 0ull;
+                vy[k] = i < P.n_blk ? ld_coherent(&bs[2 * i + 1]) : 0ull;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t i = i0 + k * BLOCK + tid;
-                fa += v[k].x;
-                ff += v[k].y;
-                if (i < P.n_blk && (v[k].x | v[k].y)) bs[i] = make_ulonglong2(0ull, 0ull);
+                fa += vx[k];
+                ff += vy[k];
+                if (i < P.n_blk && (vx[k] | vy[k])) {
+                    bs[2 * i] = 0ull;
+                    bs[2 * i + 1] = 0ull;
+                }
             }
         }
     }
-    Best best{0ull, 0u, EMPTY, 0u, 0u};
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
         const Best e = best_load_coherent(&P.partials[i]);
         if (best_gt(e, best)) best = e;
@@ -2133,10 +1870,13 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
         d.c_is_new = is_new;
         d.iter += 1;
         *st = d;
+#ifdef YB_PROFILE_SCAN
+        g_launch_prof[((d.iter - 1u) & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
+#endif
     }
     YB_SEL_STAMP(7);
 }
-__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P); }
+__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P, Best{0ull, 0u, EMPTY, 0u, 0u}); }
 
 // ================================================================ loading words into tiles
 struct LoadParams {
@@ -2240,101 +1980,109 @@ __global__ __launch_bounds__(BLOCK) void k_sum_u32(const uint32_t *p, unsigned l
 }
 
 // ================================================================ candidate argmax (exact, without reading the whole table)
-// Invariant kept between two host rebuilds: every slot whose count is >= T is in cand[] or has its `touched` bit set.
-//   - k_cand_rebuild (host, every check interval): cand = all slots with count >= T, T = 0.8 x the last best count;
-//   - counts only go UP through gt_add, which sets the touched bit; k_argmax_cand evaluates every touched slot,
-//     appends the ones that reached T and clears the bits.
-// So max over (cand U touched) is the true maximum -- with all its ties -- whenever that maximum is >= T.  If it is
-// not (the best count decayed below T, or cand[] overflowed), k_select stops with HALT_RESCAN and the host finishes
-// the batch with the full scan.  The best count is non-increasing over merges, so T is refreshed about every 64.
+// Invariant kept between two host rebuilds: every slot whose count is >= T is on the candidate list.
+//   - k_cand_rebuild (host, now and then): list = all slots with count >= T, T a little below the current best count;
+//   - counts only go UP through gt_bump, which appends a slot when its count reaches T (cand_note).
+// So the maximum over the list is the true maximum -- with all its ties -- whenever that maximum is >= T.  If it is
+// not (the best count decayed below T, or the list overflowed), the selection stops with HALT_RESCAN and the host
+// redoes that merge with the full scan.  The best count is non-increasing over merges.
 struct CandParams {
     PairTable table;
     const uint32_t *rank;
     Best *partials;
     DevState *st;
     CandState *cs;
-    uint2 *cand;       // (slot, key) of every candidate: the key rides along so that count and ranks are one round trip
     uint32_t *ticket;  // != NULL: the last workgroup to finish runs the selection itself (no k_select launch)
     SelectParams sel;
 };
 
-// (count and key are requested together: this kernel is a chain of dependent round trips, not a bandwidth problem)
-__device__ __forceinline__ void cand_eval(const CandParams &P, uint32_t s, Best &best) {
-    const long long cn = (long long)P.table.cnt[s];
-    const uint32_t k = P.table.keys[s];
-    if (cn <= 0 || (unsigned long long)cn < best.cnt || k == EMPTY) return;
-    Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
-    if (best_gt(e, best)) best = e;
+// Best entry among list[first, first + step, ...) -- four entries per thread in flight (count, key and both ranks of an
+// entry are one round trip: the key rides in the list).  Every load goes past the caches: in the fused form the list,
+// the counts and the ranks were written by other workgroups of the same launch.
+__device__ __forceinline__ Best cand_list_best(const PairTable &t, const uint32_t *rank, uint32_t n, uint32_t first, uint32_t step) {
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
+    for (uint32_t i0 = first; i0 < n; i0 += 4u * step) {
+        unsigned long long e[4], cn[4];
+        uint32_t rl[4], rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * step;
+            e[k] = i < n ? ld_coherent(&t.cand_list[i]) : ~0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cn[k] = 0ull;
+            rl[k] = rr[k] = 0u;
+            if (e[k] != ~0ull) {
+                const uint32_t key = (uint32_t)(e[k] >> 32);
+                cn[k] = ld_coherent(&t.cnt[(uint32_t)e[k]]);
+                rl[k] = ld_coherent(&rank[key >> 16]);
+                rr[k] = ld_coherent(&rank[key & 0xffffu]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((long long)cn[k] <= 0) continue;
+            const Best b{cn[k], (rl[k] << 16) | rr[k], (uint32_t)(e[k] >> 32), (uint32_t)e[k], 0u};
+            if (best_gt(b, best)) best = b;
+        }
+    }
+    return best;
 }
 
-constexpr int ARGMAX_SLOTS = 2048; // touched slots a workgroup of k_argmax_cand collects before dealing them out
+// True in exactly one workgroup of the launch: the one that finishes last.  Every workgroup of the grid calls it once,
+// when everything it wrote has been acknowledged.  The counter is sharded 8 ways (workgroup b and b + 8 usually share an
+// XCD) with a second level of 8 arrivals: several hundred workgroups finishing within a few microseconds would otherwise
+// queue on one address (~12 ns per atomic).  Counters reset themselves.
+constexpr int TICKET_STRIDE = 32; // u32 words: one 128-B line per counter
+constexpr int TICKET_WORDS = 9 * TICKET_STRIDE;
+__device__ __forceinline__ bool last_workgroup(uint32_t *ticket) {
+    __shared__ uint32_t s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t shard = blockIdx.x & 7u, n_shards = min(8u, gridDim.x);
+        const uint32_t mine = (gridDim.x - shard + 7u) >> 3; // workgroups of this shard
+        uint32_t last = 0;
+        if (__hip_atomic_fetch_add(&ticket[shard * TICKET_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u) {
+            st_coherent(&ticket[shard * TICKET_STRIDE], 0u);
+            if (__hip_atomic_fetch_add(&ticket[8 * TICKET_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1u) {
+                st_coherent(&ticket[8 * TICKET_STRIDE], 0u);
+                last = 1;
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// Tail of the fused per-merge launch (k_apply / k_scan_skip with a ticket): the workgroup that finishes last has every
+// table update of this merge behind it; it finds the next best pair on the candidate list and runs the selection --
+// what k_argmax_cand does as a launch of its own.
+struct FuseParams {
+    uint32_t *ticket; // NULL: not fused (the selection is a separate launch)
+    SelectParams sel;
+};
+// (call it from ONE place per kernel: the selection is ~9 KB of code, and these launches start with a cold instruction cache)
+__device__ __forceinline__ void fused_select_tail(const FuseParams &F) {
+    if (!F.ticket) return;
+    if (!last_workgroup(F.ticket)) return;
+    const uint32_t n = min(ld_coherent(&F.sel.cs->n), CAND_CAP);
+    const Best best = cand_list_best(F.sel.table, F.sel.tt.rank, n, threadIdx.x, BLOCK);
+    select_body(F.sel, best);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     __shared__ Best s_b[WPB];
-    __shared__ uint32_t s_last, s_nslots;
-    __shared__ uint32_t s_slots[ARGMAX_SLOTS];
-    if (threadIdx.x == 0) s_nslots = 0;
-    __syncthreads();
 #ifdef YB_PROFILE_SCAN
     if (blockIdx.x == 0) YB_SEL_STAMP(0);
     if (blockIdx.x == 0) YB_SEL_STAMP(8);
 #endif
-    const uint32_t stop = P.st->done | P.st->halt; // (these three loads do not depend on each other: one round trip)
-    const unsigned long long T = P.cs->T;
-    const uint32_t n0 = min(P.cs->n_seen, CAND_CAP); // (not n: see CandState)
-#ifdef YB_PROFILE_SCAN
-    if (blockIdx.x == 0 && (stop | (uint32_t)T | n0) != 0xdeadbeefu) YB_SEL_STAMP(10);
-#endif
+    const uint32_t stop = P.st->done | P.st->halt; // (these loads do not depend on each other: one round trip)
+    const uint32_t n0 = min(P.cs->n, CAND_CAP);    // (complete: nothing updates the table while this kernel runs)
     if (!stop) {
-        Best best{0ull, 0u, EMPTY, 0u, 0u};
-        const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x, nth = gridDim.x * BLOCK;
-        for (uint32_t i = tid; i < n0; i += nth) {
-            const uint2 e = P.cand[i]; // a slot keeps its key for as long as the table lives
-            const long long cn = (long long)P.table.cnt[e.x];
-            const uint32_t rl = P.rank[e.y >> 16], rr = P.rank[e.y & 0xffffu];
-            if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
-            const Best b{(unsigned long long)cn, (rl << 16) | rr, e.y, e.x, 0u};
-            if (best_gt(b, best)) best = b;
-        }
-#ifdef YB_PROFILE_SCAN
-        if (blockIdx.x == 0 && best.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11);
-#endif
-        // The slots whose count went up.  The bitmap is read four words at a time (it is allocated in multiples of 16 B);
-        // the set bits are first collected in LDS and then dealt to the threads one slot each: evaluating a slot is two
-        // dependent round trips (count + key, then the ranks), and a thread that owned several bits used to walk them one
-        // after the other while its neighbours had none.
-        auto visit = [&](uint32_t s) {
-            cand_eval(P, s, best);
-            if (P.table.cnt[s] >= T && (long long)P.table.cnt[s] > 0) {
-                const uint32_t bit = 1u << (s & 31);
-                if (!(atomicOr(&P.table.incand[s >> 5], bit) & bit)) {
-                    const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-                    if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else __hip_atomic_store(&P.cs->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        };
-        const uint32_t words4 = touched_words(P.table.cap) >> 2;
-        uint4 *t4 = reinterpret_cast<uint4 *>(P.table.touched);
-        for (uint32_t w4 = tid; w4 < words4; w4 += nth) {
-            const uint4 b4 = t4[w4];
-            if (!(b4.x | b4.y | b4.z | b4.w)) continue;
-            t4[w4] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t bits = q == 0 ? b4.x : q == 1 ? b4.y : q == 2 ? b4.z : b4.w;
-                const uint32_t w = (w4 << 2) + (uint32_t)q;
-                while (bits) {
-                    const uint32_t s = (w << 5) + (uint32_t)(__ffs((int)bits) - 1);
-                    bits &= bits - 1;
-                    const uint32_t k = atomicAdd(&s_nslots, 1u);
-                    if (k < (uint32_t)ARGMAX_SLOTS) s_slots[k] = s; else visit(s); // (list full: this thread does it)
-                }
-            }
-        }
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < min(s_nslots, (uint32_t)ARGMAX_SLOTS); k += BLOCK) visit(s_slots[k]);
-#ifdef YB_PROFILE_SCAN
-        if (blockIdx.x == 0 && best.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(12);
-#endif
+        Best best = cand_list_best(P.table, P.rank, n0, blockIdx.x * BLOCK + threadIdx.x, gridDim.x * BLOCK);
         best = best_wave_reduce(best);
         const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
         if (lane == 0) s_b[wib] = best;
@@ -2350,20 +2098,13 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     }
     if (!P.ticket) return;
     // The workgroup that finishes last does the selection.  No __threadfence (an L2 write-back on this part): what
-    // the selection reads from THIS kernel -- the partials and the overflow flag -- goes through device-scope
-    // accesses; each workgroup waits for its own to be acknowledged before it takes its ticket.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s_last = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    select_body(P.sel);
+    // the selection reads from THIS kernel -- the partials -- goes through device-scope accesses; each workgroup waits
+    // for its own to be acknowledged before it takes its ticket.
+    if (!last_workgroup(P.ticket)) return;
+    select_body(P.sel, Best{0ull, 0u, EMPTY, 0u, 0u});
 }
 
-// cand = every slot with count >= cs->T (the bitmaps were cleared by the host)
+// list = every slot with count >= cs->T (the bitmap was cleared by the host)
 __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
     const unsigned long long T = P.cs->T;
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < P.table.cap; s += gridDim.x * BLOCK) {
@@ -2371,8 +2112,329 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
         if (cn <= 0 || (unsigned long long)cn < T) continue;
         atomicOr(&P.table.incand[s >> 5], 1u << (s & 31));
         const uint32_t idx = atomicAdd(&P.cs->n, 1u);
-        if (idx < CAND_CAP) P.cand[idx] = make_uint2(s, P.table.keys[s]); else P.cs->overflow = 1u;
+        if (idx < CAND_CAP) P.table.cand_list[idx] = (unsigned long long)s | ((unsigned long long)P.table.keys[s] << 32); else P.cs->overflow = 1u;
     }
+}
+
+// ================================================================ the per-merge launches (they end with the fused selection)
+// ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
+// (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
+template <bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F) {
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
+    __shared__ unsigned long long s_cnt[2];
+
+    DevState *st = P.st;
+    if (st->done | st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
+    // workgroups [0, apply_blocks) apply the merge; the rest of the grid does k_rank_update's work in the same launch
+    if (blockIdx.x >= apply_blocks) {
+        rank_update_block(R, blockIdx.x - apply_blocks);
+    } else {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
+    const uint32_t mk = C.mk;
+    agg_init(C.agg);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    WaveLds &W = s_w[wib];
+    wave_lds_init(W, lane);
+    __syncthreads();
+
+    unsigned long long wave_sites = 0; // wave-uniform
+    unsigned long long wave_freed = 0; // slots removed from this wave's tiles
+    const uint32_t stride = apply_blocks * WPB;
+    const uint32_t n_tiles = P.n_tiles;
+    // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
+    // next tile's 2 x 16 B per lane are in flight while the current tile is examined.
+    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
+        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
+        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
+        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
+        TileRegs nxt = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t tile = batch + i * stride;
+            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
+            const TileRegs r = nxt;
+            if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
+            if (len == 0) continue;
+            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+        }
+    }
+#ifdef YB_PROFILE_SLOW
+    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
+#endif
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    }
+    fused_select_tail(F);
+}
+
+// Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
+// tile's signature (12 B per tile: length + the 64-bit block that holds the pair's bits); the tiles that may contain
+// the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
+#ifdef YB_PROFILE_SCAN
+#define YB_LAUNCH_START(it) do { if (threadIdx.x == 0) atomicMin(&g_launch_prof[((it) & 0xFFFFu) * 4 + 0], wall_clock64()); } while (0)
+#define YB_LAUNCH_END(it) do { if (threadIdx.x == 0) atomicMax(&g_launch_prof[((it) & 0xFFFFu) * 4 + 1], wall_clock64()); } while (0)
+__device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];
+#define YB_SCAN_STAMP(i)                                                                       \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < MAX_LISTS_PROF) g_scan_prof[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define YB_SCAN_STAMP(i) do { } while (0)
+#define YB_LAUNCH_START(it) do { } while (0)
+#define YB_LAUNCH_END(it) do { } while (0)
+#endif
+struct ScanSkipParams {
+    ScanParams S;
+    ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
+    unsigned long long *blk_read; // [scan_blocks] tiles actually read (statistics; plain stores)
+    uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
+    uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
+    uint32_t dense_cap;
+    uint32_t kt;                  // signature tests per thread: a workgroup takes SCAN_CHUNK * kt consecutive tiles at a time
+    RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
+    FuseParams F;                 // FULL form: the workgroup that finishes last selects the next merge (ticket != NULL)
+};
+
+// INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
+// (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
+// FULL (sparse merges): the rest is rewritten here too (slow_tile) -- the few tiles involved do not need k_slow's
+// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.  In this form
+// matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
+// already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
+template <bool INLINE, bool FULL, bool WEIGHTED>
+__device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // false: stop flag set, nothing done (grid-uniform)
+    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
+    constexpr bool REWRITES = INLINE || FULL;
+    static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
+    __shared__ uint32_t s_n, s_hits, s_nrew;
+    __shared__ uint2 s_list[SCAN_CHUNK * SCAN_KT_MAX];
+    __shared__ uint2 s_rew[REWRITES ? SCAN_CHUNK * SCAN_KT_MAX : 1];
+    __shared__ uint32_t s_keys[REWRITES ? AGG_N : 1];
+    __shared__ AggV s_vals[REWRITES ? AGG_N : 1];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? WPB : 1];
+    __shared__ unsigned long long s_cnt[2];
+    const ScanParams &P = Q.S;
+    DevState *st = P.st;
+    YB_SCAN_STAMP(0);
+    // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
+    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c;
+    if (st_stop) return false; // (the same answer in every workgroup: nobody takes a ticket)
+#ifdef YB_PROFILE_SCAN
+    const uint32_t prof_it = st->iter;
+    YB_LAUNCH_START(prof_it);
+#endif
+    if (blockIdx.x >= Q.scan_blocks) {
+        rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
+        YB_SCAN_STAMP(7);
+        YB_LAUNCH_END(prof_it);
+        return true;
+    }
+    const uint32_t n_blocks = Q.scan_blocks;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st_a, st_b, st_c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    const uint32_t a = C.a, b = C.b;
+    const uint32_t mk = yb_memkey(a, b);
+    C.mk = mk;
+    C.self = yb_pairkey(a, b);
+    const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
+    const bool single_ok = INLINE && a != b;
+    const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
+    if (REWRITES) agg_init(C.agg);
+    WaveLds &W = s_w[FULL ? wib : 0];
+    if (FULL) wave_lds_init(W, lane);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        s_hits = 0;
+        s_nrew = 0;
+    }
+    __syncthreads();
+    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
+    unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
+    const uint32_t kt = Q.kt;
+    const uint32_t chunk = SCAN_CHUNK * kt;
+    const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
+    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
+        // all of this thread's signature words are requested before the first one is looked at
+        uint32_t len[SCAN_KT_MAX];
+        bool maybe[SCAN_KT_MAX];
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
+            const uint32_t t = ch * chunk + j * SCAN_CHUNK + threadIdx.x;
+            len[j] = 0;
+            maybe[j] = false;
+            if (j < kt && t < P.n_tiles) {
+                len[j] = P.tile_len[t];
+                maybe[j] = probe.maybe(t);
+            }
+        }
+        YB_SCAN_STAMP(1);
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
+            if (j >= kt) break; // uniform
+            const bool mb = maybe[j] && len[j] != 0;
+            const unsigned long long m = __ballot(mb);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * SCAN_CHUNK + threadIdx.x, len[j]);
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        n_read += n;
+        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched (two in the
+        // FULL form: its rewrite code needs the registers, and a wave rarely has more than three candidates there)
+        constexpr bool DEEP = !FULL;
+        uint32_t j = wib;
+        uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
+        uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
+        uint2 it2 = DEEP && j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
+        TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
+        TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
+        TileRegs q2 = q1;
+        if constexpr (DEEP) q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+        while (j < n) {
+            const uint2 cur = it0;
+            const TileRegs r = q0;
+            it0 = it1;
+            q0 = q1;
+            j += WPB;
+            if constexpr (DEEP) {
+                it1 = it2;
+                q1 = q2;
+                if (j + 2 * WPB < n) {
+                    it2 = s_list[j + 2 * WPB];
+                    q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+                }
+            } else if (j + WPB < n) {
+                it1 = s_list[j + WPB];
+                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
+            }
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            // A rewrite stores to HBM, and on gfx950 stores queue in the same in-order vmcnt as this wave's prefetched
+            // loads: rewriting here would stall the scan behind every store.  Matched tiles are only noted; they are
+            // rewritten after the candidate loop, when no load of this wave is waiting behind the stores.
+            if (FULL) {
+                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
+                const unsigned long long holders = __ballot(mine != 0);
+                const int lane_s = __ffsll((long long)holders) - 1;
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
+                bool handled = false;
+                if constexpr (INLINE) {
+                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
+                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        handled = true;
+                    }
+                }
+                if (handled) {
+                } else if constexpr (FULL) {
+                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
+                } else if (lane == 0) {
+                    my_work[atomicAdd(&s_hits, 1u)] = cur;
+                }
+            } else if (do_inline) {
+                if (lane == 0) s_rew[atomicAdd(&s_nrew, 1u)] = cur;
+            } else {
+                if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
+            }
+        }
+        __syncthreads();
+        YB_SCAN_STAMP(2);
+        if (!FULL && do_inline) {
+            const uint32_t nr = s_nrew;
+            uint32_t k = wib;
+            uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
+            uint2 w1 = k + WPB < nr ? s_rew[k + WPB] : make_uint2(0u, 0u);
+            TileRegs t0 = load_tile(P.tiles, w0.x, w0.y, lane); // L2 hits: the tile was read a moment ago
+            TileRegs t1 = load_tile(P.tiles, w1.x, w1.y, lane);
+            while (k < nr) {
+                const uint2 cur = w0;
+                const TileRegs r = t0;
+                w0 = w1;
+                t0 = t1;
+                k += WPB;
+                if (k + WPB < nr) {
+                    w1 = s_rew[k + WPB];
+                    t1 = load_tile(P.tiles, w1.x, w1.y, lane);
+                }
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+                const uint32_t na = next_lane(r.va.x, b0);
+                const uint32_t nb = next_lane(r.vb.x, PADPAD);
+                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
+                const unsigned long long holders = __ballot(mine != 0);
+                const int lane_s = __ffsll((long long)holders) - 1;
+                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
+#ifdef YB_PROFILE_SCAN
+                if (k == (uint32_t)WPB) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
+#endif
+                bool handled = false;
+                if constexpr (INLINE) {
+                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
+                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        handled = true;
+                    }
+                }
+                if (handled) {
+                } else if constexpr (FULL) {
+                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
+                } else if (lane == 0) {
+                    my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
+                }
+#ifdef YB_PROFILE_SCAN
+                if (k == (uint32_t)WPB) YB_SCAN_STAMP(6);
+#endif
+            }
+            __syncthreads();
+        }
+        YB_SCAN_STAMP(3);
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_nrew = 0;
+        }
+        __syncthreads();
+    }
+    if (!FULL && Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
+        __shared__ uint32_t s_base;
+        __syncthreads();
+        const uint32_t nh = s_hits;
+        if (nh) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&st->work_total, nh);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nh; i += BLOCK)
+                if (s_base + i < Q.dense_cap) Q.dense[s_base + i] = my_work[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (!FULL) P.work_cnt[blockIdx.x] = s_hits;
+        if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
+    }
+    YB_SCAN_STAMP(4);
+    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    YB_SCAN_STAMP(7);
+    YB_LAUNCH_END(prof_it);
+    return true;
+}
+template <bool INLINE, bool FULL, bool WEIGHTED>
+__global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 4 workgroups per CU)
+    if (!scan_skip_block<INLINE, FULL, WEIGHTED>(Q)) return;
+    if constexpr (FULL) fused_select_tail(Q.F);
 }
 
 // ================================================================ table growth: re-insert live entries (count != 0)

@@ -39,7 +39,7 @@ class Stats(ctypes.Structure):
         ("load_ms", c_double), ("train_ms", c_double), ("apply_ms_sampled", c_double)] + [(n, c_uint64) for n in (
             "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")] + [
         ("scan_ms_sampled", c_double)] + [(n, c_uint64) for n in (
-            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans")]
+            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans", "fused_launches")]
 
 
 _lib = None
@@ -93,7 +93,7 @@ def lib() -> ctypes.CDLL:
         L.yabpe_comm_unique_id.argtypes = [c_void_p]
         L.yabpe_comm_init.argtypes = [c_void_p, c_int, c_int, c_void_p]
         L.yabpe_comm_init_custom.argtypes = [c_void_p, c_int, c_int, ALLGATHER_FN, c_void_p]
-        if L.yabpe_abi_version() != 1:
+        if L.yabpe_abi_version() != 2:
             raise ImportError("libyabpe.so ABI version mismatch")
         _lib = L
     return _lib
