@@ -344,7 +344,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->table.cand_list = nullptr;
     if (!optv(c, "cand_argmax", 1) || !c->table.incand || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
     const uint64_t words = incand_words(c->table.cap);
-    const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 1536));
+    const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 768));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
     CandState h{};
     for (int attempt = 0; attempt < 12; ++attempt) {
@@ -355,7 +355,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
         HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         PairTable t = c->table;
         t.cand_list = c->cand;
-        CandParams P{t, c->tt.rank, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
+        CandParams P{t, c->tt.rec, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
         hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&h, c->cand_state, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -775,7 +775,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->pt_cls);
     free_corpus(c);
     free_records(c);
-    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rank); dfree(c->tt.vset);
+    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rec); dfree(c->tt.vset);
     dfree(c->partials);
     dfree(c->st);
     dfree(c->scratch64);
@@ -817,49 +817,58 @@ int yabpe_set_vocab(yabpe_ctx *c, const uint8_t *tok_bytes, const uint32_t *tok_
         if (tok_off[b + 1] - tok_off[b] != 1 || tok_bytes[tok_off[b]] != b)
             return fail(c, YABPE_E_INVALID, "token %u must be the single byte %u (trainer.py:123-125)", b, b);
     if (n_tokens >= YB_MAX_TOKENS) return fail(c, YABPE_E_CAPACITY, "base vocabulary too large for u16 token ids");
-    const uint32_t pool_cap = (uint32_t)optv(c, "pool_bytes", 64 << 20);
+    const uint32_t pool_cap = (uint32_t)optv(c, "pool_bytes", 64 << 20) & ~3u;
     const uint32_t vset_cap = 1u << 18;
-    if (tok_off[n_tokens] > pool_cap / 2) return fail(c, YABPE_E_CAPACITY, "base vocabulary bytes exceed the token pool");
-    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rank); dfree(c->tt.vset);
+    // every token starts at a multiple of 4 in the pool (new tokens' bytes are written four at a time)
+    std::vector<uint32_t> off(n_tokens), len(n_tokens), order(n_tokens);
+    std::vector<uint8_t> pool;
+    for (uint32_t i = 0; i < n_tokens; ++i) {
+        len[i] = tok_off[i + 1] - tok_off[i];
+        off[i] = (uint32_t)pool.size();
+        pool.insert(pool.end(), tok_bytes + tok_off[i], tok_bytes + tok_off[i + 1]);
+        pool.resize((pool.size() + 3) & ~(size_t)3, 0);
+        order[i] = i;
+    }
+    if (pool.size() > pool_cap / 2) return fail(c, YABPE_E_CAPACITY, "base vocabulary bytes exceed the token pool");
+    dfree(c->tt.pool); dfree(c->tt.off); dfree(c->tt.len); dfree(c->tt.rec); dfree(c->tt.vset);
     TRY(dmalloc(c, &c->tt.pool, pool_cap));
     TRY(dmalloc(c, &c->tt.off, YB_MAX_TOKENS));
     TRY(dmalloc(c, &c->tt.len, YB_MAX_TOKENS));
-    TRY(dmalloc(c, &c->tt.rank, YB_MAX_TOKENS));
+    TRY(dmalloc(c, &c->tt.rec, YB_MAX_TOKENS));
     TRY(dmalloc(c, &c->tt.vset, vset_cap));
     c->tt.pool_cap = pool_cap;
     c->tt.vset_mask = vset_cap - 1;
-    std::vector<uint32_t> off(n_tokens), len(n_tokens), rank(n_tokens), order(n_tokens), vset(vset_cap, EMPTY);
-    for (uint32_t i = 0; i < n_tokens; ++i) {
-        off[i] = tok_off[i];
-        len[i] = tok_off[i + 1] - tok_off[i];
-        order[i] = i;
-    }
+    std::vector<TokRec> rec(n_tokens);
+    std::vector<unsigned long long> vset(vset_cap, VSET_EMPTY);
     auto cmp = [&](uint32_t x, uint32_t y) {
         uint32_t n = std::min(len[x], len[y]);
-        int d = memcmp(tok_bytes + off[x], tok_bytes + off[y], n);
+        int d = memcmp(pool.data() + off[x], pool.data() + off[y], n);
         if (d) return d < 0;
         return len[x] < len[y];
     };
     std::sort(order.begin(), order.end(), cmp);
     for (uint32_t r = 0; r < n_tokens; ++r) {
         if (r && !cmp(order[r - 1], order[r])) return fail(c, YABPE_E_INVALID, "duplicate token bytes in the base vocabulary (trainer.py:130)");
-        rank[order[r]] = r;
+        rec[order[r]].rank = r;
     }
     for (uint32_t i = 0; i < n_tokens; ++i) {
-        uint32_t s = yb_tok_hash(tok_bytes + off[i], len[i]) & c->tt.vset_mask;
-        while (vset[s] != EMPTY) s = (s + 1) & c->tt.vset_mask;
-        vset[s] = i;
+        rec[i].len = len[i];
+        rec[i].hash = yb_hash_bytes(pool.data() + off[i], len[i]);
+        uint32_t s = yb_vset_home(rec[i].hash, len[i]) & c->tt.vset_mask;
+        while (vset[s] != VSET_EMPTY) s = (s + 1) & c->tt.vset_mask;
+        vset[s] = yb_vset_entry(i, rec[i].hash);
     }
-    HIPCHK(c, hipMemcpy(c->tt.pool, tok_bytes, tok_off[n_tokens], hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->tt.pool, 0, pool_cap));
+    HIPCHK(c, hipMemcpy(c->tt.pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->tt.off, off.data(), n_tokens * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->tt.len, len.data(), n_tokens * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->tt.rank, rank.data(), n_tokens * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->tt.vset, vset.data(), (size_t)vset_cap * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.rec, rec.data(), n_tokens * sizeof(TokRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tt.vset, vset.data(), (size_t)vset_cap * 8, hipMemcpyHostToDevice));
     TRY(state_pull(c));
     DevState *h = c->st_host;
     memset(h, 0, sizeof(DevState));
     h->n_tokens = n_tokens;
-    h->pool_used = tok_off[n_tokens];
+    h->pool_used = (uint32_t)pool.size();
     TRY(state_push(c));
     c->base_tokens = n_tokens;
     c->have_vocab = true;
@@ -1081,11 +1090,11 @@ static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
     bool selected = false;
     if (c->use_cand) {
         const bool fuse = optv(c, "fuse_select", 1) != 0;
-        CandParams CP{c->table, c->tt.rank, c->partials, c->st, c->cand_state, fuse ? c->sel_ticket : nullptr, S};
+        CandParams CP{c->table, c->tt.rec, c->partials, c->st, c->cand_state, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;
     } else {
-        ArgmaxParams A{c->table, c->tt.rank, c->partials, c->st};
+        ArgmaxParams A{c->table, c->tt.rec, c->partials, c->st};
         hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
     }
     if (!selected) hipLaunchKernelGGL(k_select, dim3(1), dim3(BLOCK), 0, c->stream, S);
@@ -1338,7 +1347,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // selection is one workgroup reading all of it.
             const unsigned long long drop = prev_best > h->best_count ? prev_best - h->best_count : 0;
             const bool near_T = h->best_count < c->table.cand_T + 2 * drop + 1;
-            const bool long_list = h->cand_n > 3u * (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 1536));
+            const bool long_list = h->cand_n > std::max<uint32_t>(4u * BLOCK - 64u, (uint32_t)optv(c, "cand_target", 768));  // (one pass of the fused selection: 4 entries per thread)
             if (!c->use_cand || i - c->cand_built_at >= every || near_T || long_list) {
                 TRY(cand_rebuild(c, h->best_count));
                 c->cand_built_at = i;

@@ -1067,55 +1067,73 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
 }
 
 // ---------------------------------------------------------------- token byte strings on the device
+struct TokRec {      // 16 B per token: what the selection needs about a token, in one place
+    uint32_t rank;   // lexrank[id]: rank of the token's bytes in Python bytes order among all tokens
+    uint32_t len;    // bytes
+    unsigned long long hash; // yb_hash_bytes of its bytes
+};
 struct TokTable {
-    uint8_t *pool;
+    uint8_t *pool;   // token bytes; every token starts at a multiple of 4
     uint32_t *off;
     uint32_t *len;
-    uint32_t *rank;  // lexrank[id]
-    uint32_t *vset;  // open-addressing set of ids keyed by the token bytes
+    TokRec *rec;
+    unsigned long long *vset; // open-addressing set keyed by the token bytes: id | (hash >> 32) << 32, ~0 = empty
     uint32_t vset_mask;
     uint32_t pool_cap;
 };
+constexpr unsigned long long VSET_EMPTY = ~0ull;
 
-// Hash of a byte string from its length and its first/last <= 16 bytes (cheap for very long tokens;
-// equality is always decided by a full compare).  Must be identical on host and device.
-YB_HD uint32_t yb_tok_hash(const uint8_t *p, uint32_t n) {
-    uint32_t h = 2166136261u ^ n;
-    uint32_t m = n < 16u ? n : 16u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[i]) * 16777619u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ p[n - 1 - i]) * 16777619u;
-    h ^= h >> 15;
-    h *= 0x2c1b3c6dU;
-    h ^= h >> 12;
+// Hash of a byte string, linear in the string so that the hash of a concatenation follows from the parts without their
+// bytes: H(s) = sum (s[i] + 1) * B^(n-1-i) mod 2^64, H(xy) = H(x) * B^len(y) + H(y).  The selection creates the merged
+// token from two records (rank, len, hash) it has already loaded; equality of byte strings is still decided by a full
+// compare whenever hash and length agree.  Identical on host and device.
+constexpr unsigned long long YB_HASH_B = 0x9E3779B97F4A7C15ull | 1ull;
+YB_HD unsigned long long yb_hash_bytes(const uint8_t *p, uint32_t n) {
+    unsigned long long h = 0;
+    for (uint32_t i = 0; i < n; ++i) h = h * YB_HASH_B + (unsigned long long)(p[i] + 1u);
     return h;
 }
+YB_HD unsigned long long yb_hash_pow(uint32_t n) { // B^n
+    unsigned long long r = 1, b = YB_HASH_B;
+    while (n) {
+        if (n & 1u) r *= b;
+        b *= b;
+        n >>= 1;
+    }
+    return r;
+}
+YB_HD unsigned long long yb_hash_concat(unsigned long long hx, unsigned long long hy, uint32_t ly) { return hx * yb_hash_pow(ly) + hy; }
+YB_HD uint32_t yb_vset_home(unsigned long long h, uint32_t len) { // slot of a byte string (before masking)
+    unsigned long long x = h ^ ((unsigned long long)len * 0xD1B54A32D192ED03ull);
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    return (uint32_t)x;
+}
+YB_HD unsigned long long yb_vset_entry(uint32_t id, unsigned long long h) { return (unsigned long long)id | (h & 0xFFFFFFFF00000000ull); }
 
-// The same hash from the token's two ends: ends[k] = p[k], ends[16 + k] = p[n - 1 - k], k < min(n, 16).
-__device__ __forceinline__ uint32_t yb_tok_hash_ends(const uint8_t *ends, uint32_t n) {
-    uint32_t h = 2166136261u ^ n;
-    const uint32_t m = n < 16u ? n : 16u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ ends[i]) * 16777619u;
-    for (uint32_t i = 0; i < m; ++i) h = (h ^ ends[16u + i]) * 16777619u;
-    h ^= h >> 15;
-    h *= 0x2c1b3c6dU;
-    h ^= h >> 12;
-    return h;
+// byte i of the pool, past the caches (a token's bytes may have been written by another workgroup of this launch)
+__device__ __forceinline__ uint32_t pool_byte_coherent(const uint8_t *pool, uint32_t i) {
+    const uint32_t w = ld_coherent(reinterpret_cast<const uint32_t *>(pool) + (i >> 2));
+    return (w >> ((i & 3u) * 8u)) & 0xffu;
 }
 
-// Python bytes order: unsigned bytewise, a proper prefix sorts lower.
-__device__ __forceinline__ int tok_cmp(const TokTable &tt, uint32_t x, uint32_t y) {
-    const uint8_t *px = tt.pool + tt.off[x], *py = tt.pool + tt.off[y];
-    const uint32_t lx = tt.len[x], ly = tt.len[y];
-    const uint32_t n = lx < ly ? lx : ly;
+// Python bytes order: unsigned bytewise, a proper prefix sorts lower.  Compares token t with the concatenation a + b
+// (the token a merge has just created; its own bytes may not be in the pool yet).
+__device__ __forceinline__ int tok_cmp_concat(const TokTable &tt, uint32_t t, uint32_t a, uint32_t b) {
+    const uint8_t *pt = tt.pool + tt.off[t], *pa = tt.pool + tt.off[a], *pb = tt.pool + tt.off[b];
+    const uint32_t lt = tt.len[t], la = tt.len[a], lc = la + tt.len[b];
+    const uint32_t n = lt < lc ? lt : lc;
     for (uint32_t i = 0; i < n; ++i) {
-        int d = (int)px[i] - (int)py[i];
+        const int d = (int)pt[i] - (int)(i < la ? pa[i] : pb[i - la]);
         if (d) return d;
     }
-    return (lx > ly) - (lx < ly);
+    return (lt > lc) - (lt < lc);
 }
 
-// lexrank maintenance after a new token c was created: tokens above it move up by one, and c's rank is the
-// number of tokens below it.
+// lexrank maintenance after a new token c = a + b was created (a, b, c in DevState): tokens above it move up by one, and
+// c's rank is the number of tokens below it.  The first block also writes c's bytes into the pool (the selection only
+// reserved the place: it works from hashes, see select_body).
 struct RankParams {
     TokTable tt;
     DevState *st;
@@ -1126,23 +1144,36 @@ __device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t 
     DevState *st = P.st;
     if (st->done | st->halt) return;
     if (!st->c_is_new) return;
-    const uint32_t n = st->n_tokens, c = st->c;
+    const uint32_t n = st->n_tokens, c = st->c, a = st->a, b = st->b;
     if (block * BLOCK >= n) return;
     if (threadIdx.x == 0) s_less = 0;
     __syncthreads();
+    if (block == 0) { // c's bytes, four at a time (the pool is 4-byte granular), written through
+        const uint8_t *pa = P.tt.pool + P.tt.off[a], *pb = P.tt.pool + P.tt.off[b];
+        const uint32_t la = P.tt.len[a], lc = la + P.tt.len[b];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(P.tt.pool + P.tt.off[c]);
+        for (uint32_t w = threadIdx.x; w * 4u < lc; w += BLOCK) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t i = w * 4u + k;
+                if (i < lc) v |= (uint32_t)(i < la ? pa[i] : pb[i - la]) << (8u * k);
+            }
+            st_coherent(&dst[w], v);
+        }
+    }
     const uint32_t t = block * BLOCK + threadIdx.x;
     int less = 0;
     if (t < n && t != c) {
-        int cmp = tok_cmp(P.tt, t, c);
+        const int cmp = tok_cmp_concat(P.tt, t, a, b);
         if (cmp > 0)
-            st_coherent(&P.tt.rank[t], P.tt.rank[t] + 1u); // (read by the selection of the same launch in the fused form)
+            st_coherent(&P.tt.rec[t].rank, P.tt.rec[t].rank + 1u); // (read by the selection of the same launch in the fused form)
         else
             less = 1;
     }
     unsigned long long m = __ballot(less);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_less, (uint32_t)__popcll(m));
     __syncthreads();
-    if (threadIdx.x == 0 && s_less) atomicAdd(&P.tt.rank[c], s_less);
+    if (threadIdx.x == 0 && s_less) atomicAdd(&P.tt.rec[c].rank, s_less);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) { rank_update_block(P, blockIdx.x); }
@@ -1571,7 +1602,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
 
 struct ArgmaxParams {
     PairTable table;
-    const uint32_t *rank;
+    const TokRec *rec;
     Best *partials; // one per block
     DevState *st;
 };
@@ -1586,7 +1617,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_partial(ArgmaxParams P) {
         if (cn <= 0 || (unsigned long long)cn < best.cnt) continue;
         const uint32_t k = P.table.keys[s];
         if (k == EMPTY) continue;
-        Best e{(unsigned long long)cn, (P.rank[k >> 16] << 16) | P.rank[k & 0xffffu], k, s, 0u};
+        Best e{(unsigned long long)cn, (P.rec[k >> 16].rank << 16) | P.rec[k & 0xffffu].rank, k, s, 0u};
         if (best_gt(e, best)) best = e;
     }
     best = best_wave_reduce(best);
@@ -1661,22 +1692,86 @@ __device__ unsigned long long g_sel_prof[16];
 #else
 #define YB_SEL_STAMP(i) do { } while (0)
 #endif
+// What a thread knows about its best candidate: the argmax record plus the two tokens' (len, hash), so that the winner's
+// merged token needs no further trip to the token table.
+struct BestEx {
+    Best b;
+    unsigned long long hx, hy;
+    uint32_t lx, ly;
+    uint32_t have; // hx .. ly are valid
+};
+__device__ __forceinline__ BestEx best_ex_none() { return BestEx{Best{0ull, 0u, EMPTY, 0u, 0u}, 0ull, 0ull, 0u, 0u, 0u}; }
+
+// Best entry among list[first, first + step, ...), four entries per thread in flight: count, ranks, lengths and hashes of
+// an entry are one round trip (the key rides in the list, a token's record is 16 B).  Every load goes past the caches: in
+// the fused form the list, the counts and the ranks were written by other workgroups of the same launch.
+__device__ __forceinline__ void ld_rec_coherent(const TokRec *r, uint32_t &rank, uint32_t &len, unsigned long long &hash) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(r);
+    const unsigned long long a = ld_coherent(q);
+    hash = ld_coherent(q + 1);
+    rank = (uint32_t)a;
+    len = (uint32_t)(a >> 32);
+}
+__device__ __forceinline__ BestEx cand_list_best(const PairTable &t, const TokRec *rec, uint32_t n, uint32_t first, uint32_t step) {
+    BestEx best = best_ex_none();
+    for (uint32_t i0 = first; i0 < n; i0 += 4u * step) {
+        unsigned long long e[4], cn[4], hx[4], hy[4];
+        uint32_t rl[4], rr[4], lx[4], ly[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * step;
+            e[k] = i < n ? ld_coherent(&t.cand_list[i]) : ~0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cn[k] = 0ull;
+            if (i0 + (uint32_t)k * step < n) {
+                const uint32_t key = (uint32_t)(e[k] >> 32);
+                cn[k] = ld_coherent(&t.cnt[(uint32_t)e[k]]);
+                ld_rec_coherent(&rec[key >> 16], rl[k], lx[k], hx[k]);
+                ld_rec_coherent(&rec[key & 0xffffu], rr[k], ly[k], hy[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((long long)cn[k] <= 0) continue;
+            const Best b{cn[k], (rl[k] << 16) | rr[k], (uint32_t)(e[k] >> 32), (uint32_t)e[k], 0u};
+            if (best_gt(b, best.b)) best = BestEx{b, hx[k], hy[k], lx[k], ly[k], 1u};
+        }
+    }
+    return best;
+}
+
 // One workgroup: commits a pending halt, folds the apply pass's counters, reduces the argmax partials, applies the
-// stop rules and creates the merged token.  Runs as k_select, or as the tail of k_argmax_cand in its last workgroup.
-// This is a chain of dependent memory round trips on the critical path of every merge, so it is kept short: thread 0
-// works on a register copy of DevState (one load of the whole struct, one store at the end), and everything that does
-// not depend on the winner (DevState, block counters, partials) is requested in the same round.
-// `best`: this thread's candidate from the caller (the fused form evaluates the candidate list right here, in the workgroup
-// that finished last); partials of other workgroups, if any, are merged in.
-__device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
+// stop rules and creates the merged token.  Runs as k_select, as the tail of k_argmax_cand in its last workgroup, or as the
+// tail of the fused per-merge launch.  This is a chain of dependent memory round trips on the critical path of every
+// merge, so it is kept short:
+//   - thread 0 works on a register copy of DevState (one load of the whole struct, one store at the end), and everything
+//     that does not depend on the winner (DevState, block counters, partials) is requested in the same round;
+//   - the merged token is created from the two tokens' records: its hash follows from theirs (yb_hash_concat), one probe of
+//     the byte-string set says whether those bytes are already a token (trainer.py:298), and its bytes are written by the
+//     NEXT launch (rank_update_block) -- the winner's bytes are never read here unless hash and length match an entry.
+// `mine`: this thread's candidate from the caller (the fused form evaluates the candidate list right here).
+template <bool EVAL>
+__device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) {
     __shared__ Best s_b[WPB];
-    __shared__ uint32_t s_flag, s_x, s_y, s_pu, s_slot, s_cand, s_eq, s_lo[4];
-    __shared__ unsigned long long s_fold[2];
-    __shared__ uint8_t s_ends[32];
+    __shared__ uint32_t s_flag, s_slot, s_eq, s_lx, s_ly, s_have;
+    __shared__ unsigned long long s_fold[2], s_hx, s_hy, s_ent;
     DevState *st = P.st;
     const int tid = threadIdx.x;
     YB_SEL_STAMP(1);
-    DevState d; // thread 0 only
+    // ---- round trip 1: everything that depends on nothing.  EVAL (fused form): the first 4 x BLOCK entries of the
+    // candidate list and its length (the list's storage exists up to CAND_CAP; what lies past n is ignored) ...
+    unsigned long long e[4];
+    uint32_t n_list = 0;
+    if constexpr (EVAL) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
+        n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
+    }
+    // ... DevState ...
+    __shared__ DevState s_d; // thread 0's working copy (in LDS: 35 registers per lane would be allocated for one lane's sake)
+    DevState &d = s_d;
     unsigned long long candT = 0;
     uint32_t cand_over = 0;
     if (tid == 0) {
@@ -1694,31 +1789,80 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
         s_fold[0] = 0;
         s_fold[1] = 0;
         s_flag = 0;
+        s_have = 0;
     }
-    // counters of the last apply pass (one slot per workgroup), summed and cleared
+    // ... and the counters of the last apply pass (one slot per workgroup), summed and cleared further down
+    unsigned long long vx[4], vy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = k * BLOCK + tid;
+        vx[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i]) : 0ull;
+        vy[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i + 1]) : 0ull;
+    }
+    // ---- round trip 2 (EVAL): the counts of this thread's entries (the slot rides in the list) -- requested before the
+    // counters are looked at.  Round trip 3: ranks, lengths and hashes (a token's record is 16 B) only for the entries
+    // that hold the maximum count: the ranks only break ties, and every scattered load of this ONE workgroup costs a cycle
+    // of its CU's address path (4 x BLOCK entries x 5 loads were 2 us).
+    if constexpr (EVAL) {
+        __shared__ unsigned long long s_max[WPB];
+        unsigned long long cn[4], cmax = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cn[k] = 0ull;
+            if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(&P.table.cnt[(uint32_t)e[k]]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((long long)cn[k] <= 0) cn[k] = 0ull;
+            cmax = cn[k] > cmax ? cn[k] : cmax;
+        }
+        cmax = best_wave_reduce(Best{cmax, 0u, 0u, 0u, 0u}).cnt;
+        if ((tid & 63) == 0) s_max[tid >> 6] = cmax;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) cmax = s_max[w] > cmax ? s_max[w] : cmax;
+        if (cmax) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (cn[k] != cmax) continue;
+                const uint32_t key = (uint32_t)(e[k] >> 32);
+                uint32_t rl, rr, lx, ly;
+                unsigned long long hx, hy;
+                ld_rec_coherent(&P.tt.rec[key >> 16], rl, lx, hx);
+                ld_rec_coherent(&P.tt.rec[key & 0xffffu], rr, ly, hy);
+                const Best b{cn[k], (rl << 16) | rr, key, (uint32_t)e[k], 0u};
+                if (best_gt(b, mine.b)) mine = BestEx{b, hx, hy, lx, ly, 1u};
+            }
+        }
+        if (n_list > 4u * BLOCK) { // a long list (the host keeps it shorter than this): the rest, four per thread at a time
+            const BestEx more = cand_list_best(P.table, P.tt.rec, n_list, 4u * BLOCK + tid, BLOCK);
+            if (best_gt(more.b, mine.b)) mine = more;
+        }
+    }
     unsigned long long fa = 0, ff = 0;
     {
         unsigned long long *bs = P.blk_stats;
-        for (uint32_t i0 = 0; i0 < P.n_blk; i0 += 4 * BLOCK) { // four slots per thread in flight, then the clears
-            unsigned long long vx[4], vy[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = i0 + k * BLOCK + tid;
-                vx[k] = i < P.n_blk ? ld_coherent(&bs[2 * i]) : 0ull;
-                vy[k] = i < P.n_blk ? ld_coherent(&bs[2 * i + 1]) : 0ull;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * BLOCK + tid;
+            fa += vx[k];
+            ff += vy[k];
+            if (i < P.n_blk && (vx[k] | vy[k])) {
+                bs[2 * i] = 0ull;
+                bs[2 * i + 1] = 0ull;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = i0 + k * BLOCK + tid;
-                fa += vx[k];
-                ff += vy[k];
-                if (i < P.n_blk && (vx[k] | vy[k])) {
-                    bs[2 * i] = 0ull;
-                    bs[2 * i + 1] = 0ull;
-                }
+        }
+        for (uint32_t i = 4 * BLOCK + tid; i < P.n_blk; i += BLOCK) { // (grids beyond 1,024 workgroups: the dense phase)
+            const unsigned long long x = ld_coherent(&bs[2 * i]), y = ld_coherent(&bs[2 * i + 1]);
+            fa += x;
+            ff += y;
+            if (x | y) {
+                bs[2 * i] = 0ull;
+                bs[2 * i + 1] = 0ull;
             }
         }
     }
+    Best best = mine.b;
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
         const Best e = best_load_coherent(&P.partials[i]);
         if (best_gt(e, best)) best = e;
@@ -1765,10 +1909,6 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
                 // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
                 d.done = 1;
                 s_flag = 1;
-            } else {
-                s_x = best.key >> 16;
-                s_y = best.key & 0xffffu;
-                s_pu = d.pool_used;
             }
         }
         if (s_flag) *st = d;
@@ -1776,62 +1916,69 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
     __syncthreads();
     if (s_flag) return;
     YB_SEL_STAMP(3);
-    // the two tokens' lengths and offsets: four loads side by side, then one round of byte loads
-    if (tid < 2) {
-        const uint32_t t = tid ? s_y : s_x;
-        s_lo[tid] = P.tt.len[t];
-        s_lo[2 + tid] = P.tt.off[t];
+    const Best win = s_b[0];
+    const uint32_t x = win.key >> 16, y = win.key & 0xffffu;
+    // the two tokens' lengths and hashes: in the registers of the thread whose candidate won, or one more round trip
+    if (mine.have && mine.b.key == win.key && mine.b.cnt == win.cnt) { // (keys are unique on the list: one thread at most)
+        s_hx = mine.hx;
+        s_hy = mine.hy;
+        s_lx = mine.lx;
+        s_ly = mine.ly;
+        s_have = 1;
+    }
+    __syncthreads();
+    if (!s_have && tid < 2) { // (winner came from another workgroup's partial, or from a scan of the table)
+        const TokRec r = P.tt.rec[tid ? y : x];
+        if (tid) { s_hy = r.hash; s_ly = r.len; } else { s_hx = r.hash; s_lx = r.len; }
     }
     __syncthreads();
     YB_SEL_STAMP(4);
-    const uint32_t x = s_x, y = s_y, lx = s_lo[0], L = s_lo[0] + s_lo[1], pu = s_pu;
-    if ((unsigned long long)pu + L > P.tt.pool_cap) {
-        if (tid == 0) {
-            d.halt = HALT_POOL_FULL;
-            *st = d;
+    const uint32_t lx = s_lx, L = s_lx + s_ly, pu = d.pool_used; // (d: thread 0 only; pu is used by thread 0 only)
+    const unsigned long long H = yb_hash_concat(s_hx, s_hy, s_ly);
+    // "merged not in vocab" (trainer.py:298): probe the byte-string set; entries carry 32 bits of the hash, so a slot that
+    // holds another string is passed over without looking at that string
+    if (tid == 0) {
+        uint32_t slot = yb_vset_home(H, L) & P.tt.vset_mask;
+        unsigned long long e = P.tt.vset[slot];
+        while (e != VSET_EMPTY && (e >> 32) != (H >> 32)) {
+            slot = (slot + 1) & P.tt.vset_mask;
+            e = P.tt.vset[slot];
         }
-        return;
+        s_slot = slot;
+        s_ent = e;
     }
-    // merged = p0 + p1 (trainer.py:251), written at the end of the pool; its first / last 16 bytes also go to LDS,
-    // where the hash is computed without further trips to memory
-    uint8_t *mp = P.tt.pool + pu;
-    {
-        const uint8_t *px = P.tt.pool + s_lo[2], *py = P.tt.pool + s_lo[3];
-        for (uint32_t i = tid; i < L; i += BLOCK) {
-            const uint8_t v = i < lx ? px[i] : py[i - lx];
-            mp[i] = v;
-            if (i < 16u) s_ends[i] = v;
-            if (L - 1u - i < 16u) s_ends[16u + (L - 1u - i)] = v; // s_ends[16 + k] = merged[L - 1 - k]
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // "merged not in vocab" (trainer.py:298): probe the byte-string set
-    if (tid == 0) s_slot = yb_tok_hash_ends(s_ends, L) & P.tt.vset_mask;
     __syncthreads();
     YB_SEL_STAMP(5);
     uint32_t found = EMPTY;
-    while (true) {
-        if (tid == 0) {
-            s_cand = P.tt.vset[s_slot];
-            s_eq = 1;
-        }
+    while (s_ent != VSET_EMPTY) { // same 32 hash bits: compare for real (rare: the token exists already, or a 2^-32 coincidence)
+        const uint32_t cand = (uint32_t)s_ent;
+        if (tid == 0) s_eq = 1;
         __syncthreads();
-        const uint32_t cand = s_cand;
-        if (cand == EMPTY) break;
-        if (P.tt.len[cand] == L) {
-            const uint8_t *pc = P.tt.pool + P.tt.off[cand];
+        const TokRec rc = P.tt.rec[cand];
+        if (rc.len == L && rc.hash == H) {
+            const uint32_t oc = P.tt.off[cand], ox = P.tt.off[x], oy = P.tt.off[y];
             int ne = 0;
-            for (uint32_t i = tid; i < L; i += BLOCK) ne |= pc[i] != mp[i];
+            for (uint32_t i = tid; i < L; i += BLOCK)
+                ne |= pool_byte_coherent(P.tt.pool, oc + i) != pool_byte_coherent(P.tt.pool, i < lx ? ox + i : oy + (i - lx));
             if (ne) s_eq = 0; // benign race: every writer stores 0
-            __syncthreads();
-            if (s_eq) {
-                found = cand;
-                break;
-            }
+        } else if (tid == 0) {
+            s_eq = 0;
         }
         __syncthreads();
-        if (tid == 0) s_slot = (s_slot + 1) & P.tt.vset_mask;
+        if (s_eq) {
+            found = cand;
+            break;
+        }
+        if (tid == 0) { // next slot with the same 32 hash bits, or the empty slot that ends the run
+            uint32_t slot = (s_slot + 1) & P.tt.vset_mask;
+            unsigned long long e = P.tt.vset[slot];
+            while (e != VSET_EMPTY && (e >> 32) != (H >> 32)) {
+                slot = (slot + 1) & P.tt.vset_mask;
+                e = P.tt.vset[slot];
+            }
+            s_slot = slot;
+            s_ent = e;
+        }
         __syncthreads();
     }
     YB_SEL_STAMP(6);
@@ -1844,13 +1991,17 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
             d.halt = HALT_VOCAB_FULL;
             *st = d;
             return;
+        } else if ((unsigned long long)pu + L + 4ull > P.tt.pool_cap) {
+            d.halt = HALT_POOL_FULL;
+            *st = d;
+            return;
         } else {
-            cid = d.n_tokens;
+            cid = d.n_tokens; // merged = p0 + p1 (trainer.py:251): place reserved, bytes written by the next launch
             P.tt.off[cid] = pu;
             P.tt.len[cid] = L;
-            P.tt.rank[cid] = 0;
-            P.tt.vset[s_slot] = cid;
-            d.pool_used = pu + L;
+            P.tt.rec[cid] = TokRec{0u, L, H};
+            P.tt.vset[s_slot] = yb_vset_entry(cid, H);
+            d.pool_used = (pu + L + 3u) & ~3u;
             d.n_tokens = cid + 1;
             is_new = 1;
         }
@@ -1858,15 +2009,15 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
         P.rec_left[ri] = x; // merges.append(best_pair) (trainer.py:296)
         P.rec_right[ri] = y;
         P.rec_merged[ri] = cid;
-        P.rec_count[ri] = s_b[0].cnt;
+        P.rec_count[ri] = win.cnt;
         P.rec_live_slots[ri] = d.live_slots;
         // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
         // set it here once instead of letting every workgroup subtract its share from one hot address
-        P.table.cnt[s_b[0].slot] = 0ull;
+        P.table.cnt[win.slot] = 0ull;
         d.a = x;
         d.b = y;
         d.c = cid;
-        d.best_count = s_b[0].cnt;
+        d.best_count = win.cnt;
         d.c_is_new = is_new;
         d.iter += 1;
         *st = d;
@@ -1876,7 +2027,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, Best best) {
     }
     YB_SEL_STAMP(7);
 }
-__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P, Best{0ull, 0u, EMPTY, 0u, 0u}); }
+__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body<false>(P, best_ex_none()); }
 
 // ================================================================ loading words into tiles
 struct LoadParams {
@@ -1988,47 +2139,13 @@ __global__ __launch_bounds__(BLOCK) void k_sum_u32(const uint32_t *p, unsigned l
 // redoes that merge with the full scan.  The best count is non-increasing over merges.
 struct CandParams {
     PairTable table;
-    const uint32_t *rank;
+    const TokRec *rec;
     Best *partials;
     DevState *st;
     CandState *cs;
     uint32_t *ticket;  // != NULL: the last workgroup to finish runs the selection itself (no k_select launch)
     SelectParams sel;
 };
-
-// Best entry among list[first, first + step, ...) -- four entries per thread in flight (count, key and both ranks of an
-// entry are one round trip: the key rides in the list).  Every load goes past the caches: in the fused form the list,
-// the counts and the ranks were written by other workgroups of the same launch.
-__device__ __forceinline__ Best cand_list_best(const PairTable &t, const uint32_t *rank, uint32_t n, uint32_t first, uint32_t step) {
-    Best best{0ull, 0u, EMPTY, 0u, 0u};
-    for (uint32_t i0 = first; i0 < n; i0 += 4u * step) {
-        unsigned long long e[4], cn[4];
-        uint32_t rl[4], rr[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = i0 + (uint32_t)k * step;
-            e[k] = i < n ? ld_coherent(&t.cand_list[i]) : ~0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cn[k] = 0ull;
-            rl[k] = rr[k] = 0u;
-            if (e[k] != ~0ull) {
-                const uint32_t key = (uint32_t)(e[k] >> 32);
-                cn[k] = ld_coherent(&t.cnt[(uint32_t)e[k]]);
-                rl[k] = ld_coherent(&rank[key >> 16]);
-                rr[k] = ld_coherent(&rank[key & 0xffffu]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((long long)cn[k] <= 0) continue;
-            const Best b{cn[k], (rl[k] << 16) | rr[k], (uint32_t)(e[k] >> 32), (uint32_t)e[k], 0u};
-            if (best_gt(b, best)) best = b;
-        }
-    }
-    return best;
-}
 
 // True in exactly one workgroup of the launch: the one that finishes last.  Every workgroup of the grid calls it once,
 // when everything it wrote has been acknowledged.  The counter is sharded 8 ways (workgroup b and b + 8 usually share an
@@ -2067,10 +2184,10 @@ struct FuseParams {
 // (call it from ONE place per kernel: the selection is ~9 KB of code, and these launches start with a cold instruction cache)
 __device__ __forceinline__ void fused_select_tail(const FuseParams &F) {
     if (!F.ticket) return;
+    YB_SEL_STAMP(0);
     if (!last_workgroup(F.ticket)) return;
-    const uint32_t n = min(ld_coherent(&F.sel.cs->n), CAND_CAP);
-    const Best best = cand_list_best(F.sel.table, F.sel.tt.rank, n, threadIdx.x, BLOCK);
-    select_body(F.sel, best);
+    YB_SEL_STAMP(8);
+    select_body<true>(F.sel, best_ex_none());
 }
 
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
@@ -2080,9 +2197,8 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     if (blockIdx.x == 0) YB_SEL_STAMP(8);
 #endif
     const uint32_t stop = P.st->done | P.st->halt; // (these loads do not depend on each other: one round trip)
-    const uint32_t n0 = min(P.cs->n, CAND_CAP);    // (complete: nothing updates the table while this kernel runs)
-    if (!stop) {
-        Best best = cand_list_best(P.table, P.rank, n0, blockIdx.x * BLOCK + threadIdx.x, gridDim.x * BLOCK);
+    if (!stop) { // (the list is complete: nothing updates the table while this kernel runs)
+        Best best = cand_list_best(P.table, P.rec, min(P.cs->n, CAND_CAP), blockIdx.x * BLOCK + threadIdx.x, gridDim.x * BLOCK).b;
         best = best_wave_reduce(best);
         const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
         if (lane == 0) s_b[wib] = best;
@@ -2101,7 +2217,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     // the selection reads from THIS kernel -- the partials -- goes through device-scope accesses; each workgroup waits
     // for its own to be acknowledged before it takes its ticket.
     if (!last_workgroup(P.ticket)) return;
-    select_body(P.sel, Best{0ull, 0u, EMPTY, 0u, 0u});
+    select_body<false>(P.sel, best_ex_none());
 }
 
 // list = every slot with count >= cs->T (the bitmap was cleared by the host)
