@@ -924,15 +924,21 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
     }
     wave_sync();
     YB_STAMP(2);
-    // ---- compaction: every kept element moves left by the number of dropped elements before it
-    uint32_t dropped;
-    {
-        uint32_t pre = bitmap_prefix(lane < 32 ? W.dmask[lane & 31] : 0u, lane, &dropped);
-        if (lane < 32) W.dpref[lane] = pre;
-    }
-    wave_sync();
+    // ---- compaction: every kept element moves left by the number of dropped elements before it.  Out of the registers:
+    // a lane still holds its 2 x 8 slots; it counts what it keeps, one DPP prefix sum over the lanes gives its two output
+    // offsets (segment A's slots come first), and it scatters its kept slots into the LDS image -- 16 independent 2-byte
+    // writes per lane and no round trip in between.  (Position-parallel rounds over the staged tile, 64 slots at a time,
+    // were 32 dependent LDS trips per tile: the bound of the dense phase.)
     uint16_t *outb = W.stage + 8; // (all reads of the staged tokens are done: the site loop is behind us)
-    const uint32_t new_len = len - dropped;
+    const uint32_t dA2 = reinterpret_cast<const uint8_t *>(W.dmask)[lane], dB2 = reinterpret_cast<const uint8_t *>(W.dmask)[64 + lane];
+    const uint32_t vA = (uint32_t)pA >= len ? 0u : ((uint32_t)pA + 8u <= len ? 0xffu : (1u << (len - (uint32_t)pA)) - 1u);
+    const uint32_t vB = (uint32_t)pB >= len ? 0u : ((uint32_t)pB + 8u <= len ? 0xffu : (1u << (len - (uint32_t)pB)) - 1u);
+    const uint32_t keepA = ~dA2 & vA, keepB = ~dB2 & vB;
+    const uint32_t kA = __popc(keepA), kB = __popc(keepB);
+    const uint32_t inc = wave_inclusive_sum(kA | (kB << 16));
+    const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
+    const uint32_t new_len = (tot & 0xffffu) + (tot >> 16);
+    const uint32_t dropped = len - new_len;
     uint32_t first_drop = CAP; // first changed position: 16-B groups before it are unchanged in HBM
     {
         const uint32_t dw = lane < 32 ? W.dmask[lane & 31] : 0u;
@@ -944,23 +950,17 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
         // a site at p rewrites slot p (a -> c) and drops p+1: the first CHANGED slot can be first_drop - 1
         if (first_drop > 0) first_drop -= 1;
     }
-    // Position-parallel, in place: in round k lane l handles position 64k + l, so LDS reads and writes of a round
-    // touch consecutive addresses (no bank conflicts); an element never moves right, and every round reads its 64
-    // inputs before writing, so later rounds still find their inputs untouched.  Rounds before the first change are
-    // skipped: their slots already hold the right values (only 16-B groups from first_drop on are stored to HBM).
     {
-        const int k0 = (int)(first_drop >> 6), k1 = (int)((len + 63u) >> 6);
-        for (int k = k0; k < k1; ++k) {
-            const int p = k * 64 + lane;
-            const uint32_t v = stg[8 + p];
-            const uint32_t dw = W.dmask[p >> 5], mw = W.mbits[1 + (p >> 5)];
-            const uint32_t below = (1u << (p & 31)) - 1u;
-            const bool drop = ((dw >> (p & 31)) & 1u) || (uint32_t)p >= len;
-            const uint32_t dst = (uint32_t)p - (W.dpref[p >> 5] + __popc(dw & below));
-            const uint32_t val = ((mw >> (p & 31)) & 1u) ? c : v;
-            wave_sync();
-            if (!drop) outb[dst] = (uint16_t)val;
-            wave_sync();
+        uint32_t oA = (inc & 0xffffu) - kA, oB = (tot & 0xffffu) + (inc >> 16) - kB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if ((keepA >> j) & 1u) outb[oA] = (uint16_t)(((mA >> j) & 1u) ? c : elem16(r.va, j));
+            oA += (keepA >> j) & 1u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if ((keepB >> j) & 1u) outb[oB] = (uint16_t)(((mB >> j) & 1u) ? c : elem16(r.vb, j));
+            oB += (keepB >> j) & 1u;
         }
     }
     const uint32_t pad_end = (new_len + 7u) & ~7u;
