@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Dev tool (needs libyabpe_scanprof.so): per-merge timeline of the fused launches from device wall-clock stamps --
+"""Dev tool (needs libyabpe_launchprof.so: make -C yet-another-bpe_amd/csrc libyabpe_launchprof.so): per-merge timeline of the fused launches from device wall-clock stamps --
 first workgroup start, last workgroup end, selection end -- and from them the time BETWEEN launches (end of the
 selection of launch i -> first workgroup of launch i+1), which no in-kernel stamp and no rocprof duration shows alone."""
 import ctypes, os, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
-os.environ["YABPE_LIB"] = str(REPO / "yet-another-bpe_amd/csrc/libyabpe_scanprof.so")
+os.environ["YABPE_LIB"] = str(REPO / "yet-another-bpe_amd/csrc/libyabpe_launchprof.so")
 sys.path.insert(0, str(REPO / "yet-another-bpe_amd"))
 import numpy as np
 from yet_another_bpe import _native, synth

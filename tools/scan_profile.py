@@ -36,12 +36,12 @@ with _native.Context() as g:
             print(f"span scan blocks: first start 0, last start {us(scan[:,0].max()-t0):.2f}, last end {us(scan[:,7].max()-t0):.2f} us")
             if len(rank):
                 print(f"rank blocks: start {us(rank[:,0].min()-t0):.2f}..{us(rank[:,0].max()-t0):.2f}, end max {us(rank[:,7].max()-t0):.2f}, dur mean {us((rank[:,7]-rank[:,0]).mean()):.2f} max {us((rank[:,7]-rank[:,0]).max()):.2f}")
-            names = ["start->sig tested", "sig->candidates matched", "cand->rewrites done", "rewrites->loop left", "flush (epilogue)"]
-            idx = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 7)]
+            names = ["start->merge arrived", "merge->LDS initialised", "LDS init->sig tested", "sig->candidates matched", "cand->rewrites done", "rewrites->loop left", "flush (epilogue)"]
+            idx = [(0, 5), (5, 6), (6, 1), (1, 2), (2, 3), (3, 4), (4, 7)]
             for nm, (a, b) in zip(names, idx):
                 d = us(scan[:, b] - scan[:, a])
                 print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
-            w0 = scan[(scan[:, 5] > scan[:, 2]) & (scan[:, 6] > scan[:, 5])]  # wave 0 had a rewrite in this launch
+            w0 = []
             if len(w0):
                 for nm, (a, b) in (("wave 0: reload arrives", (2, 5)), ("wave 0: first rewrite", (5, 6))):
                     d = us(w0[:, b] - w0[:, a])

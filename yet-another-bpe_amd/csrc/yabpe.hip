@@ -557,11 +557,11 @@ int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
         unsigned long long bad = (c->st_host->halt_req != 0 || c->st_host->table_entries * 2 > cap) ? 1 : 0, any_bad = 0;
         TRY(comm_max(c, bad, &any_bad));  // replicas differ in layout: all ranks retry together
         if (!any_bad) {
-            if (!shrunk && c->st_host->table_entries * 8 < cap && cap > (1ull << 16)) {
-                // far too roomy (the argmax reads every slot each merge): count once more at ~2x the entries
-                // (the entry count is the same on every rank, so all ranks take this branch together)
+            if (!shrunk && c->st_host->table_entries * 32 < cap && cap > (1ull << 16)) {
+                // far too roomy (scans of the table -- candidate rebuilds, the fallback argmax -- read every slot): count
+                // once more at ~8x the entries (the entry count is the same on every rank, so all ranks take this branch together)
                 shrunk = true;
-                cap = std::max<uint64_t>(c->st_host->table_entries * 2, 1ull << 16);
+                cap = std::max<uint64_t>(c->st_host->table_entries * 8, 1ull << 16);
                 continue;
             }
             c->stats.table_rebuilds++;
@@ -1139,7 +1139,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     };
     if (c->n_tiles) {
         ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats,
-                      c->split_mode ? c->sig : nullptr, c->sig_stride};  // signatures are maintained in the split form only
+                      c->split_mode ? c->sig : nullptr, c->sig_stride, (uint32_t)optv(c, "cas_first", 0)};  // signatures are maintained in the split form only
         if (!c->split_mode) {
             const FuseParams F = fuse_params(apply_grid);
             c->blk_used = std::max(c->blk_used, apply_grid);
@@ -1447,8 +1447,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             break;
         }
         // housekeeping between batches
-        if (h->table_entries * 10 > c->table_cap * 7)  // > 70 % full; same decision on every rank
-            TRY(table_grow(c, std::max<uint64_t>(h->table_entries * 2, 1ull << 16)));
+        // kept at 12-30 % load: a key that is not at its home slot costs the flush of every merge a dependent trip (the
+        // 1 GiB job: 1.60 s at 50-70 % load, 1.42 s at 12-30 %), and the table is scanned only now and then (candidate
+        // rebuilds).  Same decision on every rank.
+        if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
+            TRY(table_grow(c, std::max<uint64_t>(h->table_entries * (uint64_t)std::max<int64_t>(2, optv(c, "table_grow_x", 8)), 1ull << 16)));
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
             TRY(retile_flat(c));

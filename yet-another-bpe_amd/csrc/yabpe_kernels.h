@@ -221,8 +221,7 @@ __device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t
 
 // `inserted`: optional per-thread counter of new keys; the caller then adds its wave's total to *t.entries itself (one
 // atomic per wave on that one hot address instead of one per new key).
-__device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
-    uint32_t s = pt_home(t, key);
+__device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t s, uint32_t *inserted) {
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
         uint32_t k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == EMPTY) {
@@ -240,6 +239,9 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
     }
     // (a per-rank delta table that runs out of probes is grown together with the exchange buffers, not the replica)
     atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
+}
+__device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
+    gt_add_from(t, st, key, d, pt_home(t, key), inserted);
 }
 
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
@@ -340,12 +342,16 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
 }
 
 template <class V>
-__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st) {
+__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
     // every thread owns AGG_N / BLOCK entries; the table keys at their home slots are requested together, so that the
-    // usual case (the key sits at its home slot) costs one round trip for all of them
+    // usual case (the key sits at its home slot) costs one round trip for all of them.  newtok: the token this merge
+    // created (EMPTY: none) -- a pair that contains it cannot be in the table yet, so its home slot is claimed with the
+    // compare-and-swap right away instead of being looked at first (one dependent trip fewer for half of a sparse
+    // merge's deltas: every site brings two such pairs).
     constexpr int PER = AGG_N / BLOCK;
     uint32_t k[PER], home[PER], tk[PER];
     long long v[PER];
+    uint32_t ins = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = threadIdx.x + q * BLOCK;
@@ -359,17 +365,26 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
         tk[q] = EMPTY;
         if (v[q] != 0) {
             home[q] = pt_home(t, k[q]);
-            tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((k[q] >> 16) == newtok || (k[q] & 0xffffu) == newtok) {
+                tk[q] = atomicCAS(&t.keys[home[q]], EMPTY, k[q]);
+                if (tk[q] == EMPTY) {
+                    tk[q] = k[q];
+                    ++ins;
+                }
+            } else {
+                tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    uint32_t ins = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         if (v[q] == 0) continue;
         if (tk[q] == k[q]) {
             gt_bump(t, home[q], k[q], v[q]);
+        } else if (tk[q] == EMPTY) {
+            gt_add_from(t, st, k[q], v[q], home[q], &ins);
         } else {
-            gt_add(t, st, k[q], v[q], &ins);
+            gt_add_from(t, st, k[q], v[q], pt_next(t, home[q]), &ins); // (home holds another key)
         }
     }
     // new keys of this wave (ins <= PER per thread): three ballots give the total
@@ -520,6 +535,7 @@ struct ApplyParams {
     unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
     unsigned long long *sig;       // tile signatures (may be NULL)
     uint32_t sig_stride;
+    uint32_t cas_first;            // flush: claim the home slot of a pair that contains the new token without looking first
 };
 
 // lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
@@ -993,7 +1009,7 @@ __device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
 // per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
 template <class AggV>
 __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> agg, DevState *st, unsigned long long *s_cnt,
-                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane) {
+                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane, uint32_t newtok = EMPTY) {
     if (lane == 0) {
         if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
         if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
@@ -1003,7 +1019,7 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
         st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]); // (it may run in this very launch)
         st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
     }
-    agg_flush(agg, P.out, st);
+    agg_flush(agg, P.out, st, newtok);
 }
 
 // ---------------------------------------------------------------- split form, pass 1: pure streaming scan
@@ -2253,6 +2269,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    const uint32_t newtok = (st->c_is_new && P.cas_first) ? C.c : EMPTY;
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
     const uint32_t mk = C.mk;
@@ -2290,7 +2307,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 #ifdef YB_PROFILE_SLOW
     if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
 #endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, newtok);
     }
     fused_select_tail(F);
 }
@@ -2299,8 +2316,13 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 // tile's signature (12 B per tile: length + the 64-bit block that holds the pair's bits); the tiles that may contain
 // the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
 #ifdef YB_PROFILE_SCAN
+#ifdef YB_PROFILE_LAUNCH // (its own build: these same-address atomics sit in front of the workgroups' loads and distort the phase stamps)
 #define YB_LAUNCH_START(it) do { if (threadIdx.x == 0) atomicMin(&g_launch_prof[((it) & 0xFFFFu) * 4 + 0], wall_clock64()); } while (0)
 #define YB_LAUNCH_END(it) do { if (threadIdx.x == 0) atomicMax(&g_launch_prof[((it) & 0xFFFFu) * 4 + 1], wall_clock64()); } while (0)
+#else
+#define YB_LAUNCH_START(it) do { } while (0)
+#define YB_LAUNCH_END(it) do { } while (0)
+#endif
 __device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];
 #define YB_SCAN_STAMP(i)                                                                       \
     do {                                                                                       \
@@ -2345,9 +2367,10 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     DevState *st = P.st;
     YB_SCAN_STAMP(0);
     // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
-    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c;
+    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c, st_new = st->c_is_new;
     if (st_stop) return false; // (the same answer in every workgroup: nobody takes a ticket)
-#ifdef YB_PROFILE_SCAN
+    if (FULL) YB_SCAN_STAMP(5); // (profile build: the merge has arrived)
+#ifdef YB_PROFILE_LAUNCH
     const uint32_t prof_it = st->iter;
     YB_LAUNCH_START(prof_it);
 #endif
@@ -2379,6 +2402,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         s_nrew = 0;
     }
     __syncthreads();
+    if (FULL) YB_SCAN_STAMP(6); // (profile build: LDS tables initialised)
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t kt = Q.kt;
@@ -2542,7 +2566,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
     }
     YB_SCAN_STAMP(4);
-    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane, (st_new && Q.A.cas_first) ? st_c : EMPTY);
     YB_SCAN_STAMP(7);
     YB_LAUNCH_END(prof_it);
     return true;
