@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BPE training hot path on MI355X: merges/s (+ corpus bytes/s) to 32k merges on the 1 GiB
-synthetic byte corpus of SURVEY.md 8(d) config 3, with the apply kernel's HBM roofline and a CPU baseline.
+synthetic byte corpus of SURVEY.md 8(d) config 3, with the bound of each phase of the timed job -- the HBM roofline of
+the streaming phase (fused k_apply, whole iterations) and the dependent-trip floor of the sparse phase (k_scan_skip) -- and
+the reference's algorithm in pure Python on the host as the CPU baseline.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -31,30 +33,50 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(ctx, pb, po, n_words, n_bytes, merges, budget_bytes, specials, max_seconds=20.0):
-    """C port of the reference algorithm (oracle/), 1 core, on the first `budget_bytes` of the same corpus."""
+def _leading_words(ctx, pb, po, n_words, budget_bytes):
     import numpy as np
 
-    from oracle import oracle
-
-    # number of leading words whose bytes fit the budget
     off_all = ctx.d2h(po, min(n_words + 1, budget_bytes // 2 + 2) * 8, dtype=np.uint64)
     k = int(np.searchsorted(off_all, budget_bytes, side="right")) - 1
     k = max(1, min(k, len(off_all) - 1))
     off = off_all[: k + 1].copy()
-    flat = ctx.d2h(pb, int(off[-1]))
+    return ctx.d2h(pb, int(off[-1])), off, k
+
+
+def cpu_baseline(ctx, pb, po, n_words, merges, budget_bytes, specials, max_seconds=20.0):
+    """The reference's merge loop restated in pure Python with its own data structures (oracle/py_trainer.py: dict of pair
+    counts, dict pair -> set of words, max over all pairs per iteration), ONE core -- the loop is single-threaded in the
+    reference too (trainer.py:241-300) -- on the first `budget_bytes` of the same corpus, merge loop capped at max_seconds."""
+    from oracle import py_trainer
+
+    flat, off, k = _leading_words(ctx, pb, po, n_words, budget_bytes)
+    fb, o = flat.tobytes(), off.tolist()
     t0 = time.time()
-    vocab, mg, info = oracle.train_flat(flat, off, 257 + merges, 1, specials, return_ids=True, max_seconds=max_seconds)
+    words = [fb[o[i]:o[i + 1]] for i in range(k)]
+    t_build = time.time() - t0
+    t0 = time.time()
+    _vocab, mg = py_trainer.merge_loop(words, 257 + merges, 1, specials, max_seconds=max_seconds)
     dt = time.time() - t0
     return {
-        "value": round(len(mg) / dt, 2), "unit": "merges/s", "cores": 1, "kind": "port",
-        "sample": f"first {int(off[-1])} bytes ({k} words, {info['unique_words']} unique) of the same corpus, "
-                  f"{len(mg)} merges in {dt:.1f} s (word pooling + pair count included; merge loop stopped after {max_seconds:.0f} s); C port of the reference's incremental algorithm (oracle/bpe_oracle.c); "
-                  f"host has {os.cpu_count()} cores",
+        "value": round(len(mg) / dt, 3), "unit": "merges/s", "cores": 1, "kind": "port",
+        "sample": f"first {int(off[-1])} bytes ({k} words) of the same corpus: {len(mg)} merges in {dt:.1f} s (word pooling and the initial pair "
+                  f"count included, the loop stopped after {max_seconds:.0f} s; slicing the words took another {t_build:.1f} s); pure-Python "
+                  f"restatement of the reference's trainer with its dict/set/max structures (oracle/py_trainer.py, pinned on the "
+                  f"reference-made golden vectors); host has {os.cpu_count()} cores, the loop uses 1",
         "corpus_bytes_per_sec": round(int(off[-1]) / dt, 1),
-        "full_job_once": "the same C port on the WHOLE 1 GiB / 32,000-merge job, run once when its result was pinned "
-                         "(tests/golden/g7_config3_meta.json): 754 s on one core of the build container = 42 merges/s",
-    }, (flat, off, mg)
+    }
+
+
+def cpu_baseline_c_port(ctx, pb, po, n_words, merges, budget_bytes, specials, max_seconds=10.0):
+    """The C port of the same algorithm (oracle/bpe_oracle.c, the parity oracle), 1 core, same kind of bounded sample."""
+    from oracle import oracle
+
+    flat, off, k = _leading_words(ctx, pb, po, n_words, budget_bytes)
+    t0 = time.time()
+    _vocab, mg, info = oracle.train_flat(flat, off, 257 + merges, 1, specials, return_ids=True, max_seconds=max_seconds)
+    dt = time.time() - t0
+    return {"value": round(len(mg) / dt, 2), "unit": "merges/s", "cores": 1, "kind": "port (C)",
+            "sample": f"first {int(off[-1])} bytes ({k} words, {info['unique_words']} unique): {len(mg)} merges in {dt:.1f} s (loop stopped after {max_seconds:.0f} s)"}
 
 
 def main() -> None:
@@ -64,9 +86,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--target-mib", type=int, default=1024)
     ap.add_argument("--merges", type=int, default=32000)
-    ap.add_argument("--event-sample", type=int, default=16, help="time every Nth apply launch with HIP events (0 = off)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=32)
-    ap.add_argument("--roofline-merges", type=int, default=2500, help="merges of the auxiliary full-scan pass (0 = skip it)")
+    ap.add_argument("--event-sample", type=int, default=64, help="time every Nth sparse-phase launch with HIP events (0 = off)")
+    ap.add_argument("--event-sample-dense", type=int, default=2, help="... every Nth launch of the streaming phase (fused k_apply)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--roofline-merges", type=int, default=1200, help="merges of the auxiliary scan-only pass (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup-line", action="store_true")
     ap.add_argument("--no-pretok-line", action="store_true")
@@ -119,6 +142,7 @@ def main() -> None:
             return runner.run(args.merges, 1, dedup=dedup, event_sample=event_sample)
         with _native.Context(local_rank) as ctx:
             ctx.set_option("event_sample", event_sample)
+            ctx.set_option("event_sample_dense", args.event_sample_dense if event_sample else 0)
             ctx.set_vocab(base)
             ctx.load_words_ptr(pb, po, n_words, dedup=dedup)
             left, right, merged, count = ctx.train(args.merges, 1)
@@ -169,30 +193,78 @@ def main() -> None:
                    "live_slots_final": st["live_slots"], "retiles": st["retiles"], "table_entries": st["table_entries"],
                    "table_capacity": st["table_capacity"], "table_rebuilds": st["table_rebuilds"], "long_words": st["n_long_words"]},
     }
-    # ---- roofline.  The production path scans through a tile-level skip index (k_scan_skip reads ~1/6 of the stream),
-    # so its time is not an HBM-streaming figure.  The HBM roofline is measured on the plain streaming form of the same
-    # pass (k_scan, skip index off: one coalesced read of the whole live token stream per merge, exactly the unit of
-    # SURVEY 8d) in a short auxiliary run on the same resident corpus, timed live with HIP events.
-    if st["apply_launches_sampled"] and st["scan_skip_launches"]:
-        n_l = st["scan_launches_sampled"]
-        secs = st["scan_ms_sampled"] / 1000.0
-        tiles_read = st["scan_skip_tiles_read"] / max(1, st["scan_skip_launches"])
-        out["skip_scan"] = {
-            "kernel": "k_scan_skip", "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / max(1, n_l), 2),
-            "full_stream_equivalent_GBps": round(st["scan_algo_bytes_sampled"] / secs / 1e9, 1) if n_l else None,
-            "avg_fraction_of_tiles_read": round(tiles_read / max(1, st["n_tiles"]), 4),
-            "apply_phase_avg_us": round(1e3 * st["apply_ms_sampled"] / st["apply_launches_sampled"], 2),
-            "note": "k_scan_skip tests 12 B per tile (length + one 64-bit signature word) and reads only tiles that may hold the pair; "
-                    "full_stream_equivalent = sum 2*(T_i+W) / time, i.e. what a full scan would have had to sustain",
+    if world > 1:
+        out["exchange"] = {"all_gathers": st["exchanges"], "bytes_received_per_merge": st["exchange_bytes"], "record_capacity_per_rank": st["exchange_cap_records"],
+                           "buffer_growths": st["exchange_growths"],
+                           "note": "per merge: apply launch (deltas leave as records) -> one all-gather of [header | records] -> one launch that adds "
+                                   "every rank's records to the replica and selects the next merge"}
+    # ---- what bounds the timed job.  It has two phases:
+    #   streaming (the first few hundred merges, most tiles change): ONE fused launch per merge, k_apply -- a coalesced read of
+    #   the whole live token stream + rewrite + pair-table update + the selection of the next merge.  HBM-bound by design:
+    #   `roofline` = sum of A_i = 2 (T_i + W) over its event-timed launches / their summed time (whole iterations).
+    #   sparse (the rest: a tile-level skip index finds the ~1 % of the tiles that hold the pair): ONE fused launch per merge,
+    #   k_scan_skip -- a chain of dependent memory trips, not a streaming kernel.  `latency` = its measured time per merge
+    #   against a floor built from pieces measured on this device in this run (yabpe_latency_probe).
+    phase_ms = {"streaming": round(st["train_ms"] - st["sparse_ms"], 2), "sparse": round(st["sparse_ms"], 2)}
+    out["device_ms"]["phases"] = phase_ms
+    if st["dense_launches_sampled"]:
+        n_l = st["dense_launches_sampled"]
+        secs = st["dense_ms_sampled"] / 1000.0
+        algo, actual = st["dense_algo_bytes_sampled"], st["dense_actual_bytes_sampled"]
+        achieved = algo / secs / 1e9
+        out["roofline"] = {
+            "kernel": "k_apply (fused per-merge launch: scan + rewrite + table update + selection)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / n_l, 2), "algo_bytes_per_launch": algo // n_l,
+            "actual_stream_bytes_per_launch": actual // n_l, "actual_stream_GBps": round(actual / secs / 1e9, 1),
+            "share_of_merge_loop_time": round(phase_ms["streaming"] / max(st["train_ms"], 1e-9), 4),
+            "measured_on": f"the timed job itself: every {args.event_sample_dense}th launch of its streaming phase "
+                           f"({st['merges_done'] - st['sparse_merges']} merges), HIP events on the library's stream",
+            "note": "achieved = sum of 2*(T_i+W) over the timed launches / their summed duration, whole iterations (T_i live tokens, W words; "
+                    "SURVEY 8d); actual_* = the u16 slots really read (single-token words leave the stream).  traffic: PMC counters cannot be "
+                    "collected inside this run; the rocprofv3 --pmc summary for this kernel is kept under profiles/ (see traffic_profile)",
         }
+        pmc = sorted((REPO / "profiles").glob("r*_pmc_k_apply_summary.json"))
+        if pmc and args.target_mib == 1024 and world == 1:
+            d = json.loads(pmc[-1].read_text())
+            out["roofline"]["traffic_profile"] = {"file": f"profiles/{pmc[-1].name}", "traffic_bytes_per_launch": int(d["traffic_bytes_per_launch"]),
+                                                  "note": "from that committed profile, NOT measured in this run"}
+    if st["sparse_merges"] and rank == 0:
+        lat = gen.latency_probe()
+        n_load, n_coh, n_atomic = 4, 4, 3
+        floor = lat["launch_gap_us"] + n_load * lat["load_trip_us"] + n_coh * lat["coherent_trip_us"] + n_atomic * lat["atomic_trip_us"]
+        achieved_us = 1000.0 * st["sparse_ms"] / st["sparse_merges"]
+        out["latency"] = {
+            "kernel": "k_scan_skip (fused per-merge launch of the sparse phase)", "bound": "dependent memory trips",
+            "floor_us_per_merge": round(floor, 2), "achieved_us_per_merge": round(achieved_us, 2), "frac": round(floor / achieved_us, 4),
+            "merges": st["sparse_merges"], "share_of_merge_loop_time": round(phase_ms["sparse"] / max(st["train_ms"], 1e-9), 4),
+            "second_half_us_per_merge": round(1000.0 * st["tail_ms"] / max(1, st["tail_merges"]), 2),
+            "second_half_frac": round(floor / (1000.0 * st["tail_ms"] / max(1, st["tail_merges"])), 4) if st["tail_merges"] else None,
+            "pieces_us": {k: round(v, 3) for k, v in lat.items()},
+            "model": f"floor = 1 launch boundary + {n_load} cache-missing loads (merge record, signature word, tile, byte-string set probe) + "
+                     f"{n_coh} device-scope loads (table key, candidate list, counts, records of the tied pairs) + {n_atomic} returning atomics "
+                     "(count add, two ticket levels): the dependent chain of one merge when every step takes one idle-device trip and "
+                     "compute, imbalance and queueing take nothing; achieved = the whole sparse phase (its first merges still have 10^5 "
+                     "sites each) including the host's housekeeping between batches (candidate-list and signature rebuilds, table growth, "
+                     "retile); second_half_* = the same for the last half of the merges, where a merge has a few thousand sites",
+        }
+        if st["apply_launches_sampled"] and st["scan_skip_launches"]:
+            n_l = st["scan_launches_sampled"]
+            tiles_read = st["scan_skip_tiles_read"] / max(1, st["scan_skip_launches"])
+            out["latency"]["event_timed"] = {"launches": n_l, "avg_launch_us": round(1e3 * st["scan_ms_sampled"] / max(1, n_l), 2),
+                                             "avg_fraction_of_tiles_read": round(tiles_read / max(1, st["n_tiles"]), 4)}
     aux_merges = min(args.merges, args.roofline_merges)
-    if aux_merges > 0:
+    if aux_merges > 0 and "roofline" in out:
+        # the scan alone (k_scan: the streaming match without rewrite), an auxiliary pass that is NOT on the timed path:
+        # skip index off, split form, first `aux_merges` merges of the same resident corpus
         def aux_job():
             if runner is not None:
-                return runner.run(aux_merges, 1, event_sample=4, options={"skip_index": 0})
+                return runner.run(aux_merges, 1, event_sample=4, options={"skip_index": 0, "split": 1})
             with _native.Context(local_rank) as ctx:
                 ctx.set_option("event_sample", 4)
                 ctx.set_option("skip_index", 0)
+                ctx.set_option("split", 1)
                 ctx.set_vocab(base)
                 ctx.load_words_ptr(pb, po, n_words)
                 ctx.train(aux_merges, 1)
@@ -203,23 +275,12 @@ def main() -> None:
             n_l = sa["scan_launches_sampled"]
             secs = sa["scan_ms_sampled"] / 1000.0
             algo, actual = sa["scan_algo_bytes_sampled"], sa["scan_actual_bytes_sampled"]
-            achieved = algo / secs / 1e9
-            out["roofline"] = {
-                "kernel": "k_scan", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / n_l, 2),
-                "algo_bytes_per_launch": algo // n_l, "actual_stream_bytes_per_launch": actual // n_l,
-                "actual_stream_GBps": round(actual / secs / 1e9, 1), "actual_frac_of_peak": round(actual / secs / 1e9 / HBM_PEAK_GBS, 4),
-                "measured_on": f"auxiliary pass: same corpus, skip index off, first {aux_merges} merges, every 4th k_scan launch timed",
-                "note": "achieved = sum 2*(T_i+W) over the HIP-event-timed k_scan launches / their summed duration (SURVEY 8d: T_i live "
-                        "tokens, W words); actual_* = the u16 slots really read (single-token words are dropped from the stream)",
+            out["roofline"]["scan_only"] = {
+                "kernel": "k_scan", "frac": round(algo / secs / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(algo / secs / 1e9, 1),
+                "actual_stream_GBps": round(actual / secs / 1e9, 1), "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / n_l, 2),
+                "note": f"auxiliary pass, not on the timed path: the streaming match alone (no rewrite, no table update, no selection), skip index off, "
+                        f"first {aux_merges} merges, every 4th launch timed -- what the read side of the tiling can do",
             }
-            pmc = sorted((REPO / "profiles").glob("r*_pmc_k_scan_summary.json"))
-            if pmc and args.target_mib == 1024 and world == 1:
-                d = json.loads(pmc[-1].read_text())
-                out["roofline"]["traffic"] = int(d["traffic_bytes_per_launch"])
-                out["roofline"]["traffic_source"] = (f"profiles/{pmc[-1].name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                                                     "FETCH x2 gfx950 correction) on k_scan, same corpus, same merges")
     if rank == 0 and not args.no_dedup_line and world == 1:
         t1 = time.perf_counter()
         rd = one_job(True, 0)
@@ -253,13 +314,18 @@ def main() -> None:
                 dt = time.perf_counter() - t1
                 cpu_pt = {"MB_per_sec": round(len(sample) / dt / 1e6, 2), "cores": 1, "kind": "reference dependency (regex.findall)",
                           "sample": f"first {len(sample)} bytes of the same text, {n_cpu} pre-tokens in {dt:.2f} s"}
+            import numpy as np
+
+            _dt, do2, nw2 = pt.pretokenize(tb, n_bytes=tn, special_tokens=["<|endoftext|>"])
+            same_offsets = bool(nw2 == tw and np.array_equal(pt.d2h(do2, (nw2 + 1) * 8, dtype=np.uint64), pt.d2h(_to, (tw + 1) * 8, dtype=np.uint64)))
+            pt.pretokenize_free()
             out["pretokenize"] = {"GB_per_sec": round(tn / best / 1e9, 2), "ms": round(best * 1e3, 2), "text_bytes": tn, "pretokens": nw_pt,
-                                  "equals_generator_words": bool(nw_pt == tw), "cpu_baseline": cpu_pt,
+                                  "offsets_equal_generator_words": same_offsets, "cpu_baseline": cpu_pt,
                                   "note": "yabpe_pretokenize (UTF-8 validation + GPT-2 split + special tokens -> word offsets in HBM), "
                                           "wall time incl. scratch allocation, best of 3; not part of `value`"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N=1 item)
-        cb, (cflat, coff, cmg) = cpu_baseline(gen, pb, po, n_words, n_bytes, args.merges, args.cpu_sample_mib << 20, specials)
-        out["cpu_baseline"] = cb
+        out["cpu_baseline"] = cpu_baseline(gen, pb, po, n_words, args.merges, args.cpu_sample_mib << 20, specials)
+        out["cpu_baseline_c_port"] = cpu_baseline_c_port(gen, pb, po, n_words, args.merges, 32 << 20, specials)
     if runner is not None:
         runner.close()
     gen.close()

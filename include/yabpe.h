@@ -118,6 +118,20 @@ typedef struct yabpe_stats_t {
     uint64_t cand_rescans;
     /* fused per-merge launches: apply of merge i + selection of merge i+1 in one kernel (the production form) */
     uint64_t fused_launches;
+    /* the streaming phase: event-timed launches of the fused k_apply (whole iteration when the selection is fused in) */
+    double dense_ms_sampled;
+    uint64_t dense_launches_sampled;
+    uint64_t dense_algo_bytes_sampled;   /* sum of 2*(T_i + W) over them */
+    uint64_t dense_actual_bytes_sampled; /* sum of the bytes of live slots + tile lengths they read */
+    /* the sparse phase (skip index): device time from the switch to the end of the last yabpe_train call, merges applied in it */
+    double sparse_ms;
+    uint64_t sparse_merges;
+    /* the second half of each yabpe_train call's merges (few sites per merge: the latency-bound regime) */
+    double tail_ms;
+    uint64_t tail_merges;
+    /* multi-GPU: all-gathers of [header | records] buffers (one per merge), bytes every rank receives per exchange, record
+       capacity per rank, times the buffers had to grow (a merge produced more records than fit: global recount) */
+    uint64_t exchanges, exchange_bytes, exchange_cap_records, exchange_growths;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */
@@ -127,6 +141,16 @@ int yabpe_iter_log(yabpe_ctx *ctx, uint64_t *out_sites, uint64_t *out_live_slots
    Nth launch): iteration index (relative to the call), duration of the whole apply phase and of its streaming
    kernel (k_scan / k_scan_skip, or the fused k_apply) in microseconds. */
 int yabpe_event_log(yabpe_ctx *ctx, uint32_t *out_iter, float *out_us, float *out_scan_us, uint32_t cap, uint32_t *out_n);
+
+/* Latency pieces of one sparse merge, measured on the (otherwise idle) device: what the floor of the per-merge launch is
+   built from (bench.py prints the model).  All in microseconds. */
+typedef struct yabpe_latency_t {
+    double launch_gap_us;       /* back-to-back dependent launches of an empty kernel on one stream, per launch */
+    double load_trip_us;        /* one dependent global load that misses the caches (pointer chase, one lane) */
+    double coherent_trip_us;    /* the same with device-scope loads (hand-offs inside a launch) */
+    double atomic_trip_us;      /* one dependent returning device-scope atomic */
+} yabpe_latency_t;
+int yabpe_latency_probe(yabpe_ctx *ctx, yabpe_latency_t *out);
 
 /* Debug / self-check: recount every pair from the token stream into a scratch table and compare with the
    incrementally maintained table.  *out_mismatches = number of differing keys. */

@@ -36,7 +36,7 @@ def test_transport_callback_gloo_world2():
     assert sums[0] == sums[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_protocol_equals_single_rank(world):
     words = [b"low"] * 5 + [b"lower"] * 2 + [b"widest"] * 3 + [b"newest"] * 6 + [b"abab"] * 4 + [b"aaaa", b"aaa", b"<|endoftext|>"] * 2
     sp = ["<|endoftext|>"]

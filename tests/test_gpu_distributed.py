@@ -39,6 +39,17 @@ def test_two_ranks_one_gpu(scenario):
         assert outs[0][2] >= 1  # the overflow recovery (global recount) ran
 
 
+@pytest.mark.parametrize("scenario", ["corpus_en_flat", "synthetic_medium"])
+def test_four_ranks_one_gpu(scenario):
+    """World size 4 through the same transport (the box allows 6 processes on its card): shards, exchange buffers and the
+    fused delta-apply + selection launch with four contributors; result = the oracle's."""
+    exp = _expect(scenario)
+    outs = dist_workers.spawn(dist_workers.gpu_sharded, 4, scenario, timeout=900)
+    for merges, n_words, rebuilds, retiles in outs:
+        assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp
+    assert all(o[1] > 0 for o in outs)
+
+
 def test_rccl_transport_single_rank_smoke():
     """The real RCCL calls (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the compute stream) with a
     1-rank communicator: the exchange path runs end to end through librccl and must not change the result."""
@@ -71,13 +82,19 @@ def test_text_in_model_out_two_ranks(golden_dir, monkeypatch, tmp_path):
     pre-tokens and joins the collective merge loop; result = the single-process trainer with the same chunk size."""
     from yet_another_bpe.trainer import BBPETrainer, BBPETrainerConfig
 
-    monkeypatch.setenv("YABPE_PRETOKENIZE", "host")
+    from oracle import pretok
+
+    data = (golden_dir / "corpus.en").read_bytes()
     for chunk in (16384, 1 << 30):  # 9 chunks over 2 ranks / one chunk: the second rank holds no words at all
+        # expected: the ORACLE on the reference's chunking (trainer.py:172-198: cuts every chunk_size bytes, moved back to a
+        # UTF-8 boundary; corpus.en is ASCII, so the cuts are the multiples of the chunk size) -- regex split per chunk, C oracle
+        starts = list(range(0, len(data), chunk))
+        exp_vocab, exp_merges = oracle.merge_loop(pretok.pretokenize(data, SP, chunk_starts=starts), 700, 1, SP)
         cfg = BBPETrainerConfig(vocab_size=700, min_frequency=1, special_tokens=SP, chunk_size_bytes=chunk)
-        exp = BBPETrainer(cfg).train([golden_dir / "corpus.en"])
+        assert BBPETrainer(cfg)._chunk_ranges(golden_dir / "corpus.en") == [(s0, min(s0 + chunk, len(data))) for s0 in starts]  # the product cuts there too
         outs = dist_workers.spawn(dist_workers.gpu_text_sharded, 2, str(golden_dir / "corpus.en"), chunk, 700, SP, timeout=900)
         for merges, nv in outs:
-            assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp.merges and nv == len(exp.vocab)
+            assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp_merges and nv == len(exp_vocab)
     bad = tmp_path / "bad.txt"
     bad.write_bytes(b"good " * 5000 + b"\xff" + b" more" * 5000)
     with pytest.raises(AssertionError, match="contains invalid UTF-8 at position 25000"):

@@ -178,8 +178,8 @@ struct yabpe_ctx {
     yabpe_allgather_fn ag_fn = nullptr;  // custom transport (tests / other fabrics) instead of RCCL
     void *ag_user = nullptr;
     unsigned long long *xsmall = nullptr;  // n_ranks x u64 receive slots for small agreements
-    PairTable delta{};      // per-rank delta table (apply passes add here instead of into `table`)
-    uint8_t *xsend = nullptr, *xrecv = nullptr;
+    uint8_t *xsend = nullptr, *xrecv = nullptr;  // [DeltaHdr | xcap DeltaRec] of this rank / of every rank
+    uint64_t exchange_growths = 0;  // times the exchange buffers had to grow (a merge produced more records than fit)
     uint32_t xcap = 0;      // records per rank per exchange
     uint64_t xstride = 0;   // bytes per rank buffer
     uint64_t exchanges = 0;
@@ -297,13 +297,21 @@ void table_free(PairTable &t) {
     t.cand_cs = nullptr;
     t.cand_list = nullptr;
     t.cand_T = 0;
+    t.sink_rec = nullptr;
+    t.sink_hdr = nullptr;
+    t.sink_cap = 0;
 }
 
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
     TRY(dmalloc(c, &t.keys, cap));
     TRY(dmalloc(c, &t.cnt, cap));
     t.cap = (uint32_t)cap;
-    t.max_probe = (uint32_t)std::min<uint64_t>(cap, 2048);
+    // (multi-GPU: a replica must never give up on a probe chain on its own -- its layout differs from its peers' -- so the
+    //  chain may run over the whole table; the deterministic 80 % rule of the selection stops all ranks long before that)
+    t.max_probe = c->multi ? (uint32_t)cap : (uint32_t)std::min<uint64_t>(cap, 2048);
+    t.sink_rec = nullptr;
+    t.sink_hdr = nullptr;
+    t.sink_cap = 0;
     t.entries = entries_ctr;
     t.incand = nullptr;  // the candidate list is attached to the main table only, once it is built (cand_attach / cand_rebuild)
     t.cand_cs = nullptr;
@@ -787,7 +795,6 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->cand_state);
     dfree(c->sel_ticket);
     dfree(c->cand);
-    table_free(c->delta);
     dfree(c->xsend);
     dfree(c->xrecv);
     dfree(c->xsmall);
@@ -1042,6 +1049,14 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.apply_launches_sampled = 0;
     c->stats.apply_algo_bytes_sampled = 0;
     c->stats.apply_actual_bytes_sampled = 0;
+    c->stats.dense_ms_sampled = 0;
+    c->stats.dense_launches_sampled = 0;
+    c->stats.dense_algo_bytes_sampled = 0;
+    c->stats.dense_actual_bytes_sampled = 0;
+    c->stats.sparse_ms = 0;
+    c->stats.sparse_merges = 0;
+    c->stats.tail_ms = 0;
+    c->stats.tail_merges = 0;
     c->stats.scan_ms_sampled = 0;
     c->stats.scan_launches_sampled = 0;
     c->stats.scan_algo_bytes_sampled = 0;
@@ -1049,6 +1064,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->scan_skip_launches = 0;
     c->cand_rebuilds = c->cand_rescans = 0;
     c->fused_launches = 0;
+    c->exchanges = 0;
+    c->exchange_growths = 0;
     if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
@@ -1104,7 +1121,9 @@ static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
 
 // Can the apply launch of the merge that is selected now end with the selection of the next one?
 static bool can_fuse(yabpe_ctx *c) {
-    if (!c->use_cand || c->multi || !optv(c, "fused", 1) || !c->n_tiles) return false;
+    if (!c->use_cand || !optv(c, "fused", 1)) return false;
+    if (c->multi) return true;        // the selection rides on the launch that applies the exchanged records (k_delta_apply)
+    if (!c->n_tiles) return false;
     if (!c->split_mode) return true;  // k_apply
     return c->sig && c->sig_valid && !optv(c, "fuse_skip", 0) && c->dense_mode && optv(c, "full_skip", 1);  // k_scan_skip, FULL form
 }
@@ -1119,19 +1138,27 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     const bool rank_rides = c->n_tiles && (fuse || optv(c, "rank_rides", 1)) &&
                             (c->split_mode ? (c->sig && c->sig_valid && !optv(c, "fuse_skip", 0)) : true);
     if (!rank_rides) hipLaunchKernelGGL(k_rank_update, dim3(rank_blocks), dim3(BLOCK), 0, c->stream, R);
-    const PairTable out_table = c->multi ? c->delta : c->table;
+    // where the apply pass puts its pair-count updates: the pair table, or (multi-GPU) this rank's send buffer as records
+    PairTable out_table = c->table;
+    if (c->multi) {
+        out_table = PairTable{};
+        out_table.sink_hdr = reinterpret_cast<DeltaHdr *>(c->xsend);
+        out_table.sink_rec = reinterpret_cast<DeltaRec *>(c->xsend + 16);
+        out_table.sink_cap = c->xcap;
+    }
+    const bool fuse_kernel = fuse && !c->multi;  // the apply launch itself ends with the selection
     if (ev) {
         ev->split = c->split_mode;
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
-    if (fuse && c->n_long) {  // the long words first: the fused launch must be the last one to touch the table
+    if (fuse_kernel && c->n_long) {  // the long words first: the fused launch must be the last one to touch the table
         LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
         hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
     }
     // the fused selection folds the per-workgroup counters of THIS launch too: it must know the larger grid
     auto fuse_params = [&](uint32_t grid_now) {
         FuseParams F{};
-        if (fuse) {
+        if (fuse_kernel) {
             F.ticket = c->sel_ticket;
             F.sel = select_params(c, rec_base, 0u, std::max(c->blk_used, grid_now));
         }
@@ -1227,22 +1254,26 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
-    if (fuse) {
-        c->blk_used = 0;  // folded by the selection at the end of that launch
-        c->fused_launches++;
-    }
-    if (!fuse && c->n_long) {
+    if (!fuse_kernel && c->n_long) {
         LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
         hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
     }
     if (c->multi) {
-        // this rank's aggregated deltas -> [header | records]; one all-gather; every rank applies all of them
-        ExtractParams X{c->delta, reinterpret_cast<DeltaHdr *>(c->xsend), reinterpret_cast<DeltaRec *>(c->xsend + 16), c->xcap, c->st};
-        hipLaunchKernelGGL(k_delta_extract, dim3((uint32_t)std::max<uint64_t>(1, (uint64_t)c->delta.cap / BLOCK / 4)), dim3(BLOCK), 0, c->stream, X);
+        // Per merge: the apply launch above left this rank's updates as [header | records] in its send buffer (the
+        // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every
+        // rank's records to the replica and -- fused form -- selects the next merge in its last workgroup.
         TRY(comm_allgather(c, c->xsend, c->xrecv, c->xstride));
-        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xcap, c->xstride, c->table, c->st};
+        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xcap, c->xstride, c->table, c->st, FuseParams{}};
+        if (fuse) {
+            DA.F.ticket = c->sel_ticket;
+            DA.F.sel = select_params(c, rec_base, 0u, c->blk_used);
+        }
         hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xcap, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
         c->exchanges++;
+    }
+    if (fuse) {
+        c->blk_used = 0;  // folded by the selection at the end of that launch
+        c->fused_launches++;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1291,15 +1322,20 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
 
     const uint32_t check = (uint32_t)std::max<int64_t>(1, optv(c, "check_interval", 64));
     const uint32_t ev_sample = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample", 0));
+    const uint32_t ev_sample_dense = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample_dense", (int64_t)ev_sample));  // fused k_apply launches
     const double retile_frac = (double)optv(c, "retile_pct", 60) / 100.0;
     const uint64_t retile_min_tiles = (uint64_t)optv(c, "retile_min_tiles", 4096);
     std::vector<EventPair> used_events;
     size_t ev_next = 0;
 
-    hipEvent_t t0, t1;
+    hipEvent_t t0, t1, t_split, t_tail;
     HIPCHK(c, hipEventCreate(&t0));
     HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventCreate(&t_split));
+    HIPCHK(c, hipEventCreate(&t_tail));
     HIPCHK(c, hipEventRecord(t0, c->stream));
+    bool split_marked = false, tail_marked = false;
+    uint32_t split_at = 0, tail_at = 0;
 
     uint32_t tokens_start = h->n_tokens;
     uint32_t i = 0;
@@ -1328,6 +1364,16 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         else if (!c->split_mode && h->iter > rec_base &&
                  (c->weighted && h->sites ? h->sites : h->best_count) * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
             c->split_mode = true;
+        if (!tail_marked && i >= num_merges / 2) {  // (measurement: the second half of this call's merges)
+            tail_marked = true;
+            tail_at = i;
+            HIPCHK(c, hipEventRecord(t_tail, c->stream));
+        }
+        if (c->split_mode && !split_marked) {  // (measurement: where the streaming phase ends and the sparse phase begins)
+            split_marked = true;
+            split_at = i;
+            HIPCHK(c, hipEventRecord(t_split, c->stream));
+        }
         {
             const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
             const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
@@ -1369,7 +1415,8 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         }
         uint32_t batch_end = std::min(num_merges, i + ((i == 0 && !c->split_mode) ? std::min<uint32_t>(check, 8) : check));
         auto sample = [&](uint32_t iter_rel) -> EventPair * {
-            if (!ev_sample || (iter_rel % ev_sample) != 0) return nullptr;
+            const uint32_t every = c->split_mode ? ev_sample : ev_sample_dense;
+            if (!every || (iter_rel % every) != 0) return nullptr;
             if (ev_next == c->events.size()) {
                 EventPair n{};
                 if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess || hipEventCreate(&n.e2) != hipSuccess) return nullptr;
@@ -1423,12 +1470,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 const bool delta_full = h->halt == HALT_DELTA_FULL;
                 h->halt = 0; h->halt_req = 0;
                 TRY(state_push(c));
-                if (delta_full) {  // more distinct pairs changed in one merge than a rank can hold / send: 4x of both
+                if (delta_full) {  // a merge produced more records on some rank than its send buffer holds: 4x for everybody
                     TRY(comm_buffers(c, c->xcap * 4));
-                    const uint64_t dcap = std::min<uint64_t>((uint64_t)c->delta.cap * 4, 1ull << 24);
-                    table_free(c->delta);
-                    HIPCHK(c, hipMemsetAsync(&c->st->delta_entries, 0, 8, c->stream));
-                    TRY(table_alloc(c, c->delta, dcap, &c->st->delta_entries));
+                    c->exchange_growths++;
                 }
                 TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
                 TRY(state_pull(c));
@@ -1439,7 +1483,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
                               : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
                                                            : "device halt";
-            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(t_split); (void)hipEventDestroy(t_tail);
             return fail(c, YABPE_E_CAPACITY, "%s after %u merges", why, h->iter - rec_base);
         }
         if (h->done || (i >= num_merges && !c->pending)) {
@@ -1461,8 +1505,22 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     HIPCHK(c, hipEventSynchronize(t1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    if (split_marked) {
+        float sms = 0;
+        HIPCHK(c, hipEventElapsedTime(&sms, t_split, t1));
+        c->stats.sparse_ms += sms;
+        c->stats.sparse_merges += (h->iter - rec_base) > split_at ? (h->iter - rec_base) - split_at : 0;
+    }
+    if (tail_marked) {
+        float tms = 0;
+        HIPCHK(c, hipEventElapsedTime(&tms, t_tail, t1));
+        c->stats.tail_ms += tms;
+        c->stats.tail_merges += (h->iter - rec_base) > tail_at ? (h->iter - rec_base) - tail_at : 0;
+    }
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
+    (void)hipEventDestroy(t_split);
+    (void)hipEventDestroy(t_tail);
     c->stats.train_ms += ms;
 
     // close the log of the last iteration and fold the remaining sites into T_i
@@ -1500,6 +1558,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->ev_us.push_back(ems * 1000.0f);
             c->ev_scan_us.push_back(sms * 1000.0f);
             c->stats.apply_launches_sampled += 1;
+            if (!c->events[e].split) {  // fused k_apply: one streaming pass over the live stream + rewrite (+ selection when fused)
+                c->stats.dense_ms_sampled += ems;
+                c->stats.dense_launches_sampled += 1;
+                c->stats.dense_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
+                c->stats.dense_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
+            }
             if (c->events[e].split) {
                 c->stats.scan_ms_sampled += sms;
                 c->stats.scan_launches_sampled += 1;
@@ -1564,6 +1628,10 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.cand_rebuilds = c->cand_rebuilds;
     c->stats.cand_rescans = c->cand_rescans;
     c->stats.fused_launches = c->fused_launches;
+    c->stats.exchanges = c->exchanges;
+    c->stats.exchange_bytes = c->multi ? c->xstride * (uint64_t)c->n_ranks : 0;
+    c->stats.exchange_cap_records = c->xcap;
+    c->stats.exchange_growths = c->exchange_growths;
     c->stats.scan_skip_launches = c->scan_skip_launches;
     c->stats.scan_skip_tiles_read = 0;
     if (c->blk_read) {
@@ -1572,6 +1640,53 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
         for (auto v : br) c->stats.scan_skip_tiles_read += v;
     }
     *out = c->stats;
+    return YABPE_OK;
+}
+
+int yabpe_latency_probe(yabpe_ctx *c, yabpe_latency_t *out) {
+    if (!c || !out) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = 1u << 29;  // 2 GiB of u32: eight times the Infinity Cache, so a hop finds its line in no cache
+    uint32_t *next = nullptr, *sink = nullptr;
+    unsigned long long *ticks = nullptr;
+    TRY(dmalloc(c, &next, n));
+    TRY(dmalloc(c, &sink, 1));
+    TRY(dmalloc(c, &ticks, 1));
+    double trip[3] = {0, 0, 0};
+    const uint32_t hops = 1024;
+    for (int mode = 0; mode < 3; ++mode) {
+        // (the table is rewritten before every walk: whatever the last walk left in the caches is pushed out, and each walk is timed once, cold)
+        hipLaunchKernelGGL(k_chain_init, dim3(n / 256), dim3(256), 0, c->stream, next, n, 40503u * 4096u + 4099u + 2u * (uint32_t)mode);  // (odd: one cycle; far strides)
+        hipLaunchKernelGGL(k_chain_walk, dim3(1), dim3(1), 0, c->stream, next, hops, mode, ticks, sink);
+        HIPCHK(c, hipGetLastError());
+        unsigned long long t = 0;
+        HIPCHK(c, hipMemcpyAsync(&t, ticks, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        trip[mode] = (double)t / 100.0 / hops;
+    }
+    // dependent empty launches back to back
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    double gap = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+        const int n_launch = 400;
+        for (int k = 0; k < 50; ++k) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, c->stream, sink);
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int k = 0; k < n_launch; ++k) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, c->stream, sink);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        gap = std::min(gap, (double)ms * 1000.0 / n_launch);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    dfree(next); dfree(sink); dfree(ticks);
+    out->launch_gap_us = gap;
+    out->load_trip_us = trip[0];
+    out->coherent_trip_us = trip[1];
+    out->atomic_trip_us = trip[2];
     return YABPE_OK;
 }
 
@@ -1807,10 +1922,8 @@ static int comm_attach(yabpe_ctx *c, int rank, int n_ranks) {
     return 0;
 }
 static int comm_finish(yabpe_ctx *c) {
-    const uint64_t dcap = 1ull << optv(c, "delta_table_log2", 16);
-    TRY(table_alloc(c, c->delta, dcap, &c->st->delta_entries));
     TRY(dmalloc(c, &c->xsmall, (uint64_t)c->n_ranks));
-    TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 4096)));
+    TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 16384)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return YABPE_OK;
 }

@@ -434,4 +434,29 @@ __global__ __launch_bounds__(BLOCK) void k_retile(RetileParams P) {
     }
 }
 
+// ================================================================ latency probe (measurement; include/yabpe.h yabpe_latency_probe)
+// The pieces the per-merge launch is built from, measured on an otherwise idle device: one lane walks a chain of dependent
+// accesses through a table far larger than the caches (a random cyclic permutation), so every hop is a full trip to memory.
+//   mode 0: plain loads   mode 1: device-scope loads (past the caches; what hand-offs inside a launch use)
+//   mode 2: returning device-scope atomic adds (the adds of the aggregator flush whose results the selection needs)
+__global__ void k_chain_init(uint32_t *next, uint32_t n, uint32_t stride) { // next[i] = (i + stride) mod n: one cycle when gcd = 1
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) next[i] = (uint32_t)(((unsigned long long)i + stride) % n);
+}
+__global__ void k_chain_walk(uint32_t *next, uint32_t hops, int mode, unsigned long long *out_ticks, uint32_t *sink) {
+    uint32_t x = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (uint32_t h = 0; h < hops; ++h) {
+        if (mode == 0) x = next[x];
+        else if (mode == 1) x = __hip_atomic_load(&next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else x = atomicAdd(&next[x], 0u);
+    }
+    const unsigned long long t1 = wall_clock64();
+    *out_ticks = t1 - t0; // 100 MHz
+    *sink = x;
+}
+__global__ void k_empty(uint32_t *sink) {
+    if (threadIdx.x == 12345u) *sink = 1;
+}
+
 }  // namespace yb

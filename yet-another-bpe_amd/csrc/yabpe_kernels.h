@@ -65,6 +65,16 @@ struct DevState {
     uint32_t pad1;
 };
 
+// multi-GPU exchange records: what a rank's apply pass sends to the others (see k_delta_apply)
+struct DeltaHdr {
+    unsigned long long count; // records this rank produced (may exceed the buffer capacity: overflow, every rank sees it)
+    unsigned long long halt;  // this rank's committed halt, if any
+};
+struct DeltaRec {
+    uint32_t key, pad;
+    long long delta;
+};
+
 // candidate argmax state (see k_argmax_cand / fused_select_tail)
 constexpr uint32_t CAND_CAP = 1u << 16; // capacity of the candidate list
 struct CandState {
@@ -85,6 +95,11 @@ struct PairTable {
     CandState *cand_cs;          // list length / overflow flag
     unsigned long long *cand_list; // entries: slot | key << 32
     unsigned long long cand_T;
+    // multi-GPU: not a table at all but this rank's send buffer -- every update becomes a (key, delta) record that all
+    // ranks add to their replicas after the exchange (k_delta_apply).  keys / cnt are unused then.
+    DeltaRec *sink_rec;
+    DeltaHdr *sink_hdr;
+    uint32_t sink_cap;
 };
 // words of the `incand` bitmap of a table of `cap` slots
 YB_HD uint32_t incand_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
@@ -117,16 +132,6 @@ __device__ __forceinline__ Best best_load_coherent(const Best *p) {
     const unsigned long long c = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return Best{a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)c, 0u};
 }
-
-// multi-GPU delta exchange records (see k_delta_extract)
-struct DeltaHdr {
-    unsigned long long count; // records this rank produced (may exceed the buffer capacity: overflow)
-    unsigned long long halt;  // this rank's halt request
-};
-struct DeltaRec {
-    uint32_t key, pad;
-    long long delta;
-};
 
 __device__ __forceinline__ uint32_t hash32(uint32_t k) {
     k ^= k >> 16;
@@ -188,6 +193,18 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar): Hillis-Steele inside each row of 16
+// lanes (row_shr 1,2,4,8; lanes without a source add 0), then the row totals travel with row_bcast:15 / row_bcast:31.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // ---------------------------------------------------------------- global pair table
 // Values another workgroup of the SAME launch may read (the workgroup that finishes last runs the selection, see
 // fused_select_tail): device-scope stores and loads, coherent across the XCDs' L2s without a cache write-back.
@@ -221,7 +238,15 @@ __device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t
 
 // `inserted`: optional per-thread counter of new keys; the caller then adds its wave's total to *t.entries itself (one
 // atomic per wave on that one hot address instead of one per new key).
+__device__ __forceinline__ void sink_append(const PairTable &t, uint32_t key, long long d) {
+    const unsigned long long idx = atomicAdd(&t.sink_hdr->count, 1ull);
+    if (idx < t.sink_cap) t.sink_rec[idx] = DeltaRec{key, 0u, d}; // (past the capacity: the count itself tells every rank)
+}
 __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t s, uint32_t *inserted) {
+    if (t.sink_rec) {
+        sink_append(t, key, d);
+        return;
+    }
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
         uint32_t k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == EMPTY) {
@@ -241,7 +266,7 @@ __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, ui
     atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
 }
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
-    gt_add_from(t, st, key, d, pt_home(t, key), inserted);
+    gt_add_from(t, st, key, d, t.sink_rec ? 0u : pt_home(t, key), inserted);
 }
 
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
@@ -352,6 +377,37 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
     uint32_t k[PER], home[PER], tk[PER];
     long long v[PER];
     uint32_t ins = 0;
+    if (t.sink_rec) { // multi-GPU: the workgroup's deltas leave as records, one reservation in the send buffer per workgroup
+        __shared__ uint32_t s_wtot[WPB];
+        __shared__ unsigned long long s_sbase;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = threadIdx.x + q * BLOCK;
+            k[q] = g.keys[i];
+            v[q] = k[q] == EMPTY ? 0ll : (long long)g.vals[i];
+            mine += v[q] != 0;
+        }
+        const uint32_t inc = wave_inclusive_sum(mine);
+        const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+        if (lane == 63) s_wtot[wib] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < WPB; ++w) tot += s_wtot[w];
+            s_sbase = tot ? atomicAdd(&t.sink_hdr->count, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long at = s_sbase + (inc - mine);
+        for (int w = 0; w < wib; ++w) at += s_wtot[w];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (v[q] == 0) continue;
+            if (at < t.sink_cap) t.sink_rec[at] = DeltaRec{k[q], 0u, v[q]};
+            ++at;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = threadIdx.x + q * BLOCK;
@@ -589,18 +645,6 @@ struct MrgBits {
     const uint32_t *mbits;
     __device__ __forceinline__ int operator()(int q) const { return (int)((mbits[1 + (q >> 5)] >> (q & 31)) & 1u); }
 };
-
-// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar): Hillis-Steele inside each row of 16
-// lanes (row_shr 1,2,4,8; lanes without a source add 0), then the row totals travel with row_bcast:15 / row_bcast:31.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
-    return x;
-}
 
 // exclusive prefix of popcounts over the 32 words of a bitmap (lanes 0..31 hold one word each)
 __device__ __forceinline__ uint32_t bitmap_prefix(uint32_t word, int lane, uint32_t *total) {
@@ -1897,8 +1941,11 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     __syncthreads();
     YB_SEL_STAMP(2);
     if (tid == 0) {
-        if (P.delta_hdr) P.delta_hdr->count = 0ull;
         if (d.halt == 0 && d.halt_req != 0) d.halt = d.halt_req;
+        if (P.delta_hdr) { // this rank's send header for the next exchange
+            P.delta_hdr->count = 0ull;
+            P.delta_hdr->halt = d.halt;
+        }
         // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
         // no replica can run out of probes on its own.
         if (d.halt == 0 && d.table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d.halt = HALT_TABLE_FULL; // > 80 % full
@@ -2599,53 +2646,31 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(RehashParams P) {
 // hold identical counts and every rank selects the same merge.  A rank that must stop (overflow) says so in its
 // header: all ranks then stop at the same iteration.
 
-struct ExtractParams {
-    PairTable dt;
-    DeltaHdr *hdr;
-    DeltaRec *rec;
-    uint32_t cap;
-    DevState *st;
-};
-__global__ __launch_bounds__(BLOCK) void k_delta_extract(ExtractParams P) {
-    const uint32_t slots = P.dt.cap;
-    for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < slots; s += gridDim.x * BLOCK) {
-        const uint32_t k = P.dt.keys[s];
-        if (k == EMPTY) continue;
-        const long long v = (long long)P.dt.cnt[s];
-        P.dt.keys[s] = EMPTY; // the delta table is empty again for the next merge
-        P.dt.cnt[s] = 0ull;
-        if (v != 0) {
-            const unsigned long long idx = atomicAdd(&P.hdr->count, 1ull);
-            if (idx < P.cap) P.rec[idx] = DeltaRec{k, 0u, v};
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        P.hdr->halt = P.st->halt | P.st->halt_req;
-        P.st->delta_entries = 0ull;
-    }
-}
-
 struct DeltaApplyParams {
     const uint8_t *recv; // n_ranks buffers of stride bytes: DeltaHdr, then cap DeltaRec
     uint32_t n_ranks, cap;
     unsigned long long stride;
     PairTable table;
     DevState *st;
+    FuseParams F;        // ticket != NULL: the workgroup that finishes last selects the next merge (one launch fewer per merge)
 };
 __global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
+    if (P.st->done | P.st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
     const unsigned long long idx = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t r = (uint32_t)(idx / P.cap), j = (uint32_t)(idx % P.cap);
-    if (r >= P.n_ranks) return;
-    const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
-    const unsigned long long n = h->count;
-    if (j == 0) {
-        if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
-        else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
+    if (r < P.n_ranks) {
+        const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
+        const unsigned long long n = h->count;
+        if (j == 0) { // every rank reads every header: all of them stop at the same merge
+            if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
+            else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
+        }
+        if (j < n && j < P.cap) {
+            const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
+            gt_add(P.table, P.st, rec[j].key, rec[j].delta);
+        }
     }
-    if (j < n && j < P.cap) {
-        const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
-        gt_add(P.table, P.st, rec[j].key, rec[j].delta);
-    }
+    fused_select_tail(P.F);
 }
 
 // out[i] = sum over rows r of in[r * n + i]

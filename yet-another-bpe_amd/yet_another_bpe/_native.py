@@ -39,7 +39,14 @@ class Stats(ctypes.Structure):
         ("load_ms", c_double), ("train_ms", c_double), ("apply_ms_sampled", c_double)] + [(n, c_uint64) for n in (
             "apply_launches_sampled", "apply_algo_bytes_sampled", "apply_actual_bytes_sampled", "algo_bytes_total")] + [
         ("scan_ms_sampled", c_double)] + [(n, c_uint64) for n in (
-            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans", "fused_launches")]
+            "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans", "fused_launches")] + [
+        ("dense_ms_sampled", c_double)] + [(n, c_uint64) for n in ("dense_launches_sampled", "dense_algo_bytes_sampled", "dense_actual_bytes_sampled")] + [
+        ("sparse_ms", c_double), ("sparse_merges", c_uint64), ("tail_ms", c_double), ("tail_merges", c_uint64)] + [
+        (n, c_uint64) for n in ("exchanges", "exchange_bytes", "exchange_cap_records", "exchange_growths")]
+
+
+class Latency(ctypes.Structure):
+    _fields_ = [(n, c_double) for n in ("launch_gap_us", "load_trip_us", "coherent_trip_us", "atomic_trip_us")]
 
 
 _lib = None
@@ -50,7 +57,7 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
 SYMBOLS = [
     "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
-    "yabpe_iter_log", "yabpe_event_log", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
+    "yabpe_iter_log", "yabpe_event_log", "yabpe_latency_probe", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
     "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_pretokenize", "yabpe_pretokenize_free",
     "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
 ]
@@ -214,6 +221,12 @@ class Context:
         scan = np.zeros(max(n.value, 1), dtype=np.float32)
         self._chk(lib().yabpe_event_log(self._h, it.ctypes.data, us.ctypes.data, scan.ctypes.data, n.value, byref(n)))
         return it[:n.value], us[:n.value], scan[:n.value]
+
+    def latency_probe(self) -> dict:
+        """Measured latency pieces of one sparse merge on this device (include/yabpe.h yabpe_latency_t), microseconds."""
+        s = Latency()
+        self._chk(lib().yabpe_latency_probe(self._h, byref(s)))
+        return {f: getattr(s, f) for f, _ in Latency._fields_}
 
     def verify_table(self) -> int:
         m = c_uint64(0)
