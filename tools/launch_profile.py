@@ -23,8 +23,8 @@ with _native.Context() as g:
         ctx.train(32000, 1)
         sp = (ctypes.c_uint64 * 16)(); L.yabpe_debug_sel_profile(sp); sp = [int(v) for v in sp]
         rel = lambda i: (sp[i] - sp[0]) / 100.0
-        print("last launch, selection tail (us after its workgroup reached the ticket): ticket won %.2f | list evaluated %.2f | state+counters in %.2f | winner %.2f | records %.2f | probe %.2f | compare %.2f | end %.2f"
-              % (rel(8), rel(9), rel(2), rel(3), rel(4), rel(5), rel(6), rel(7)))
+        print("last launch, selection tail (us after its workgroup reached the ticket): ticket won %.2f | entries+length in %.2f | counts in %.2f | tie records in %.2f | state+counters folded %.2f | winner %.2f | records %.2f | probe %.2f | compare %.2f | end %.2f"
+              % (rel(8), rel(9), rel(10), rel(11), rel(2), rel(3), rel(4), rel(5), rel(6), rel(7)))
         out = np.zeros(65536 * 4, dtype=np.uint64)
         L.yabpe_debug_launch_profile(ctypes.c_void_p(out.ctypes.data), 0)
 raw = out.reshape(65536, 4)

@@ -1201,7 +1201,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 const uint32_t n256 = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
                 // sparse merges: the scan also rewrites the few tiles with several sites itself -- no k_slow launch
                 const bool full = c->dense_mode && optv(c, "full_skip", 1);
-                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * 3))
+                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * 4))
                                              : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
                 const uint32_t kt = std::min<uint32_t>(SCAN_KT_MAX, std::max<uint32_t>(1, (n256 + target - 1) / target));
                 const uint32_t chunk = SCAN_CHUNK * kt;

@@ -1829,22 +1829,31 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
         n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
     }
-    // ... DevState ...
-    __shared__ DevState s_d; // thread 0's working copy (in LDS: 35 registers per lane would be allocated for one lane's sake)
-    DevState &d = s_d;
+    // ... the fields of DevState the selection needs (thread 0 keeps them in registers and writes back what it changes,
+    // field by field: a working copy of the whole struct was 36 registers in every lane, and in LDS it made thread 0's
+    // serial part a chain of LDS round trips) ...
+    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0;
+    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0;
     unsigned long long candT = 0;
-    uint32_t cand_over = 0;
+    uint32_t cand_over = 0, cand_n = 0;
     if (tid == 0) {
-        d = *st;
+        d_iter = st->iter;
+        d_done = st->done;
+        d_halt = st->halt;
+        d_n_tokens = st->n_tokens;
+        d_pool_used = st->pool_used;
+        d_num_merges = st->num_merges;
+        d_min_freq = st->min_freq;
+        d_live_slots = st->live_slots;
+        d_tokens_now = st->tokens_now;
         // fields other workgroups of this launch may have moved (atomics): read them past the caches
-        d.halt_req = ld_coherent(&st->halt_req);
-        d.table_entries = ld_coherent(&st->table_entries);
-        d.delta_entries = ld_coherent(&st->delta_entries);
-        d.sites = ld_coherent(&st->sites);
+        d_halt_req = ld_coherent(&st->halt_req);
+        d_table_entries = ld_coherent(&st->table_entries);
+        d_sites = ld_coherent(&st->sites);
         if (P.cs) {
             candT = P.cs->T;
             cand_over = ld_coherent(&P.cs->overflow);
-            d.cand_n = ld_coherent(&P.cs->n);
+            cand_n = ld_coherent(&P.cs->n);
         }
         s_fold[0] = 0;
         s_fold[1] = 0;
@@ -1871,11 +1880,13 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             cn[k] = 0ull;
             if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(&P.table.cnt[(uint32_t)e[k]]);
         }
+        if (n_list != 0xdeadbeefu) YB_SEL_STAMP(9); // (profile build: list length + entries have arrived, counts requested)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if ((long long)cn[k] <= 0) cn[k] = 0ull;
             cmax = cn[k] > cmax ? cn[k] : cmax;
         }
+        if (cmax != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(10); // (counts have arrived)
         cmax = best_wave_reduce(Best{cmax, 0u, 0u, 0u, 0u}).cnt;
         if ((tid & 63) == 0) s_max[tid >> 6] = cmax;
         __syncthreads();
@@ -1894,6 +1905,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
                 if (best_gt(b, mine.b)) mine = BestEx{b, hx, hy, lx, ly, 1u};
             }
         }
+        if (mine.b.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11); // (records of the tied entries have arrived)
         if (n_list > 4u * BLOCK) { // a long list (the host keeps it shorter than this): the rest, four per thread at a time
             const BestEx more = cand_list_best(P.table, P.tt.rec, n_list, 4u * BLOCK + tid, BLOCK);
             if (best_gt(more.b, mine.b)) mine = more;
@@ -1941,40 +1953,46 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     __syncthreads();
     YB_SEL_STAMP(2);
     if (tid == 0) {
-        if (d.halt == 0 && d.halt_req != 0) d.halt = d.halt_req;
+        if (d_halt == 0 && d_halt_req != 0) d_halt = d_halt_req;
         if (P.delta_hdr) { // this rank's send header for the next exchange
             P.delta_hdr->count = 0ull;
-            P.delta_hdr->halt = d.halt;
+            P.delta_hdr->halt = d_halt;
         }
         // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
         // no replica can run out of probes on its own.
-        if (d.halt == 0 && d.table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d.halt = HALT_TABLE_FULL; // > 80 % full
-        for (int q = 0; q < 8; ++q) d.chunk_next[q] = 0u;
-        d.work_total = 0u;
-        d.sites += s_fold[0];
-        d.live_slots -= s_fold[1];
-        if (d.done | d.halt) {
+        if (d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full
+        d_sites += s_fold[0];
+        d_live_slots -= s_fold[1];
+        if (d_done | d_halt) {
             s_flag = 1;
         } else {
             for (int w = 1; w < WPB; ++w)
                 if (best_gt(s_b[w], best)) best = s_b[w];
             s_b[0] = best;
             // close the log entry of the previous iteration
-            const uint32_t it = d.iter;
-            if (it > P.rec_base && d.sites) P.rec_sites[it - 1 - P.rec_base] = d.sites; // (0: already closed, this is a re-run)
-            d.tokens_now -= d.sites;
-            d.sites = 0;
-            if (P.cs && it < d.num_merges && (best.cnt < candT || cand_over)) {
+            const uint32_t it = d_iter;
+            if (it > P.rec_base && d_sites) P.rec_sites[it - 1 - P.rec_base] = d_sites; // (0: already closed, this is a re-run)
+            d_tokens_now -= d_sites;
+            d_sites = 0;
+            if (P.cs && it < d_num_merges && (best.cnt < candT || cand_over)) {
                 // the candidate set no longer proves that this is the maximum: the host redoes this merge with a full scan
-                d.halt = HALT_RESCAN;
+                d_halt = HALT_RESCAN;
                 s_flag = 1;
-            } else if (it >= d.num_merges || best.cnt == 0 || best.cnt < d.min_freq) {
+            } else if (it >= d_num_merges || best.cnt == 0 || best.cnt < d_min_freq) {
                 // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
-                d.done = 1;
+                d_done = 1;
                 s_flag = 1;
             }
         }
-        if (s_flag) *st = d;
+        // what every path writes back (the rest follows when a merge has been selected)
+        st->halt = d_halt;
+        st->done = d_done;
+        st->sites = d_sites;
+        st->live_slots = d_live_slots;
+        st->tokens_now = d_tokens_now;
+        st->cand_n = cand_n;
+        st->work_total = 0u;
+        for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
     }
     __syncthreads();
     if (s_flag) return;
@@ -1996,7 +2014,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     }
     __syncthreads();
     YB_SEL_STAMP(4);
-    const uint32_t lx = s_lx, L = s_lx + s_ly, pu = d.pool_used; // (d: thread 0 only; pu is used by thread 0 only)
+    const uint32_t lx = s_lx, L = s_lx + s_ly, pu = d_pool_used; // (thread 0 only)
     const unsigned long long H = yb_hash_concat(s_hx, s_hy, s_ly);
     // "merged not in vocab" (trainer.py:298): probe the byte-string set; entries carry 32 bits of the hash, so a slot that
     // holds another string is passed over without looking at that string
@@ -2050,42 +2068,39 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         uint32_t is_new = 0;
         if (found != EMPTY) {
             cid = found; // bytes already a token: no id is consumed (trainer.py:298-300)
-        } else if (d.n_tokens >= YB_MAX_TOKENS) {
-            d.halt = HALT_VOCAB_FULL;
-            *st = d;
+        } else if (d_n_tokens >= YB_MAX_TOKENS) {
+            st->halt = HALT_VOCAB_FULL;
             return;
         } else if ((unsigned long long)pu + L + 4ull > P.tt.pool_cap) {
-            d.halt = HALT_POOL_FULL;
-            *st = d;
+            st->halt = HALT_POOL_FULL;
             return;
         } else {
-            cid = d.n_tokens; // merged = p0 + p1 (trainer.py:251): place reserved, bytes written by the next launch
+            cid = d_n_tokens; // merged = p0 + p1 (trainer.py:251): place reserved, bytes written by the next launch
             P.tt.off[cid] = pu;
             P.tt.len[cid] = L;
             P.tt.rec[cid] = TokRec{0u, L, H};
             P.tt.vset[s_slot] = yb_vset_entry(cid, H);
-            d.pool_used = (pu + L + 3u) & ~3u;
-            d.n_tokens = cid + 1;
+            st->pool_used = (pu + L + 3u) & ~3u;
+            st->n_tokens = cid + 1;
             is_new = 1;
         }
-        const uint32_t ri = d.iter - P.rec_base;
+        const uint32_t ri = d_iter - P.rec_base;
         P.rec_left[ri] = x; // merges.append(best_pair) (trainer.py:296)
         P.rec_right[ri] = y;
         P.rec_merged[ri] = cid;
         P.rec_count[ri] = win.cnt;
-        P.rec_live_slots[ri] = d.live_slots;
+        P.rec_live_slots[ri] = d_live_slots;
         // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
         // set it here once instead of letting every workgroup subtract its share from one hot address
         P.table.cnt[win.slot] = 0ull;
-        d.a = x;
-        d.b = y;
-        d.c = cid;
-        d.best_count = win.cnt;
-        d.c_is_new = is_new;
-        d.iter += 1;
-        *st = d;
-#ifdef YB_PROFILE_SCAN
-        g_launch_prof[((d.iter - 1u) & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
+        st->a = x;
+        st->b = y;
+        st->c = cid;
+        st->best_count = win.cnt;
+        st->c_is_new = is_new;
+        st->iter = d_iter + 1;
+#ifdef YB_PROFILE_LAUNCH
+        g_launch_prof[(d_iter & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
 #endif
     }
     YB_SEL_STAMP(7);
