@@ -7,6 +7,7 @@ import time
 
 import pytest
 
+from oracle import oracle
 from tests import helpers
 from yet_another_bpe.trainer import BBPEModel, BBPETrainer, BBPETrainerConfig
 
@@ -106,12 +107,44 @@ def test_train_bpe_matches_reference_fixture(golden_dir):
 
 
 def test_train_bpe_speed(golden_dir):
-    """reference tests/test_train_bpe_gpt2.py:8-24: whole run_train_bpe on corpus.en @ vocab 500 under 1.5 s
-    (HIP context creation and code-object load included when this is the first GPU call of the process)."""
-    run_train_bpe(golden_dir / "corpus.en", 300, ["<|endoftext|>"])  # first call of the process pays HIP start-up
-    t0 = time.time()
-    run_train_bpe(golden_dir / "corpus.en", 500, ["<|endoftext|>"])
-    assert time.time() - t0 < 1.5
+    """reference tests/test_train_bpe_gpt2.py:8-24: ONE run_train_bpe call on corpus.en @ vocab 500 in under 1.5 s.  Timed
+    cold, as the reference's test times its call: a child process imports the package and makes exactly that one call --
+    HIP start-up, code-object load and the first allocations are inside the timed region, nothing warms it up."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, time\n"
+        f"sys.path[:0] = [{str(helpers.GOLDEN.parent.parent)!r}, {str(helpers.GOLDEN.parent.parent / 'yet-another-bpe_amd')!r}]\n"
+        "from tests.test_gpu_api import run_train_bpe\n"
+        "t0 = time.time()\n"
+        f"vocab, merges = run_train_bpe({str(golden_dir / 'corpus.en')!r}, 500, ['<|endoftext|>'])\n"
+        "print('ELAPSED', time.time() - t0, len(merges))\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("ELAPSED")][-1].split()
+    assert int(line[2]) == 243
+    assert float(line[1]) < 1.5, f"cold run_train_bpe took {float(line[1]):.2f} s"
+
+
+def test_min_frequency_zero_or_negative_merges_to_exhaustion():
+    """The reference's stop rule is `count < min_frequency` (trainer.py:247): with min_frequency <= 0 it never fires."""
+    words = [b"abab"] * 3 + [b"abc"] * 2 + [b"xyz"]
+    for mf in (0, -3):
+        t = BBPETrainer(BBPETrainerConfig(vocab_size=400, min_frequency=mf, max_workers=1, special_tokens=["<|endoftext|>"]))
+        vocab, merges = t._merge_loop([list(w) for w in words])
+        exp_vocab, exp_merges = oracle.merge_loop(words, 400, 1, ["<|endoftext|>"])  # (every live pair has count >= 1)
+        assert merges == exp_merges and vocab == exp_vocab and len(merges) > 4
+
+
+def test_vocab_size_far_beyond_the_id_space_on_a_small_corpus():
+    """vocab_size=100000 on a corpus that runs out of pairs long before: the reference returns normally; so must this."""
+    words = helpers.corpus_en_words()[:3000]
+    t = BBPETrainer(BBPETrainerConfig(vocab_size=100_000, min_frequency=1, max_workers=1, special_tokens=["<|endoftext|>"]))
+    vocab, merges = t._merge_loop([list(w) for w in words])
+    exp_vocab, exp_merges = oracle.merge_loop(words, 100_000, 1, ["<|endoftext|>"])
+    assert merges == exp_merges and vocab == exp_vocab
 
 
 class TestTrainIntegration:

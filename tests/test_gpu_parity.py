@@ -160,7 +160,9 @@ def test_many_tiles_retile_and_table_growth():
     # the plain streaming scan (skip index off) and the always-split / never-split forms give the same result
     for opts in ({"skip_index": 0}, {"split": 1}, {"split": 0}, {"sig_rebuild_every": 3, "check_interval": 2}, {"fuse_skip": 1}, {"inline_single": 0}, {"rank_rides": 0}, {"dense_worklist": 1}, {"dense_worklist": 0}, {"cand_argmax": 0}, {"cand_min_count": 1, "check_interval": 3},
                  {"fuse_select": 0}, {"cand_rebuild_every": 1}, {"cand_rebuild_every": 100000, "check_interval": 8}, {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
-                 {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16}):
+                 {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16},
+                 {"fused": 0}, {"fused": 1, "check_interval": 3}, {"cand_target": 64, "check_interval": 4}, {"cas_first": 1}, {"table_load_pct": 70, "table_grow_x": 2},
+                 {"dense_table": 1}, {"dense_table": 1, "check_interval": 3, "cand_target": 64}, {"dense_table": 1, "fused": 0}, {"dense_table": 1, "cand_argmax": 0}):
         v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
         assert (v3, m3) == (exp_vocab, exp_merges), opts
     assert s1["scan_skip_launches"] > 0 and s1["scan_skip_tiles_read"] < s1["scan_skip_launches"] * s1["n_tiles"]
@@ -173,7 +175,7 @@ def test_weighted_layout_split_forms():
     uw, fq = helpers.pooled(words)
     exp = oracle.merge_loop(words, 257 + 1200, 1, SP)
     for opts in ({"split": 1}, {"split": 1, "dense_worklist": 1}, {"split": 1, "dense_worklist": 1, "full_skip": 0},
-                 {"split": 1, "dense_worklist": 0}, {"split": 1, "skip_index": 0}):
+                 {"split": 1, "dense_worklist": 0}, {"split": 1, "skip_index": 0}, {"dense_table": 1}, {"dense_table": 1, "split": 1, "check_interval": 5}):
         assert gpu_train(uw, fq, 257 + 1200, 1, SP, options={"verify": 1, **opts}) == exp, opts
 
 
@@ -198,11 +200,19 @@ def test_continue_training_equals_one_shot():
 
 
 def test_vocab_id_space_limit_is_reported():
-    from yet_another_bpe import _native
+    """More merges than u16 ids: fine while the corpus runs out of pairs first (the reference returns normally there,
+    e.g. vocab_size=100000 on a small corpus); a capacity error only when the loop really reaches the last id."""
+    from yet_another_bpe import _native, synth
 
     with _native.Context() as ctx:
         ctx.set_vocab(helpers.base_tokens(SP))
         ctx.load_words(*helpers.flatten([b"ab", b"cd"]))
+        left, right, merged, count = ctx.train(70_000, 1)
+        assert len(left) == 2  # exhausted, no error
+    flat, off = synth.generate(synth.SynthSpec(6 << 20, 120_000, 21, bytes(range(256)), False))  # > 65,277 merges possible
+    with _native.Context() as ctx:
+        ctx.set_vocab(helpers.base_tokens(SP))
+        ctx.load_words(flat, off, dedup=True)
         with pytest.raises(_native.YabpeError) as e:
             ctx.train(70_000, 1)
-        assert e.value.code == -4
+        assert e.value.code == -4 and "id space exhausted" in str(e.value)

@@ -167,6 +167,11 @@ struct yabpe_ctx {
     bool use_cand = false;
     uint64_t cand_rebuilds = 0, cand_rescans = 0;
     double cand_margin = 0.2;        // T = best count x (1 - margin); adapted so that the list stays short
+    // direct-indexed count matrix (c->table.dense): rows the host lists for a scan
+    uint32_t *scan_rows = nullptr;   // device, YB_MAX_TOKENS entries
+    uint32_t n_scan_rows = 0;
+    uint64_t matrix_growths = 0;
+    uint64_t local_count_cap = 0;    // multi-GPU recounts: slots of the per-rank hash table the local count goes through
     uint32_t cand_n_at_build = 0;
     // fused per-merge launch: the apply kernel of merge i ends with the selection of merge i + 1
     bool pending = false;            // a merge has been selected (recorded) and not applied yet
@@ -300,6 +305,11 @@ void table_free(PairTable &t) {
     t.sink_rec = nullptr;
     t.sink_hdr = nullptr;
     t.sink_cap = 0;
+    dfree(t.dense);
+    dfree(t.rowmax);
+    t.dense = nullptr;
+    t.rowmax = nullptr;
+    t.dense_v = 0;
 }
 
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
@@ -312,6 +322,9 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.sink_rec = nullptr;
     t.sink_hdr = nullptr;
     t.sink_cap = 0;
+    t.dense = nullptr;
+    t.rowmax = nullptr;
+    t.dense_v = 0;
     t.entries = entries_ctr;
     t.incand = nullptr;  // the candidate list is attached to the main table only, once it is built (cand_attach / cand_rebuild)
     t.cand_cs = nullptr;
@@ -322,6 +335,66 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     return 0;
 }
 
+// ---------------------------------------------------------------- direct-indexed count matrix (PairTable::dense)
+bool want_dense(yabpe_ctx *c) { return optv(c, "dense_table", 0) != 0; }  // (measured equal to the hash table at 12-30 % load: kept as an option)
+
+// a zeroed matrix with rows for `v` tokens (the rest of PairTable stays empty: no keys, no probing)
+int dense_alloc(yabpe_ctx *c, PairTable &t, uint32_t v) {
+    t = PairTable{};
+    TRY(dmalloc(c, &t.dense, tri_size(v)));
+    TRY(dmalloc(c, &t.rowmax, v));
+    t.dense_v = v;
+    t.entries = &c->st->table_entries;
+    HIPCHK(c, hipMemsetAsync(t.dense, 0, tri_size(v) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(t.rowmax, 0, (size_t)v * 8, c->stream));
+    return 0;
+}
+
+// rows for at least `need_v` tokens: a bigger matrix takes over the old rows (rows are stored one after the other, so the
+// old matrix is a prefix of the new one)
+int dense_ensure_rows(yabpe_ctx *c, uint32_t need_v) {
+    PairTable &t = c->table;
+    need_v = std::min<uint32_t>(need_v, YB_MAX_TOKENS);
+    if (!t.dense || t.dense_v >= need_v) return 0;
+    const uint32_t new_v = std::min<uint32_t>(YB_MAX_TOKENS, std::max<uint32_t>(need_v, t.dense_v + t.dense_v / 2 + 1024));
+    unsigned long long *nd = nullptr, *nr = nullptr;
+    TRY(dmalloc(c, &nd, tri_size(new_v)));
+    TRY(dmalloc(c, &nr, new_v));
+    HIPCHK(c, hipMemcpyAsync(nd, t.dense, tri_size(t.dense_v) * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(nd + tri_size(t.dense_v), 0, (tri_size(new_v) - tri_size(t.dense_v)) * 8, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nr, t.rowmax, (size_t)t.dense_v * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(nr + t.dense_v, 0, (size_t)(new_v - t.dense_v) * 8, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(t.dense);
+    dfree(t.rowmax);
+    t.dense = nd;
+    t.rowmax = nr;
+    t.dense_v = new_v;
+    c->table_cap = tri_size(new_v);
+    c->matrix_growths++;
+    return 0;
+}
+
+// The rows a scan has to read: tokens whose bound rowmax is >= `bound`, plus `extra` rows past the tokens that exist now
+// (tokens the launches of the coming batch may create: their rows are zero until then).  One small copy each way.
+int dense_list_rows(yabpe_ctx *c, uint32_t n_tokens, unsigned long long bound, uint32_t extra) {
+    const PairTable &t = c->table;
+    n_tokens = std::min(n_tokens, t.dense_v);
+    std::vector<unsigned long long> rm(n_tokens);
+    if (n_tokens) HIPCHK(c, hipMemcpyAsync(rm.data(), t.rowmax, (size_t)n_tokens * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> rows;
+    rows.reserve(n_tokens + extra);
+    for (uint32_t o = 0; o < n_tokens; ++o)
+        if (rm[o] >= bound) rows.push_back(o);
+    for (uint32_t o = n_tokens; o < std::min<uint32_t>(t.dense_v, n_tokens + extra); ++o) rows.push_back(o);
+    if (!c->scan_rows) TRY(dmalloc(c, &c->scan_rows, YB_MAX_TOKENS));
+    c->n_scan_rows = (uint32_t)rows.size();
+    if (!rows.empty()) HIPCHK(c, hipMemcpyAsync(c->scan_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // bitmap of the candidate argmax for the main table (cleared; the candidate list is rebuilt by the caller's next check)
 int cand_attach(yabpe_ctx *c) {
     c->use_cand = false;
@@ -329,9 +402,11 @@ int cand_attach(yabpe_ctx *c) {
     t.cand_cs = nullptr;
     t.cand_list = nullptr;
     if (!optv(c, "cand_argmax", 1)) return 0;
-    const uint64_t words = incand_words(t.cap);
-    if (!t.incand) TRY(dmalloc(c, &t.incand, words));
-    HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
+    if (!t.dense) {
+        const uint64_t words = incand_words(t.cap);
+        if (!t.incand) TRY(dmalloc(c, &t.incand, words));
+        HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
+    }
     if (!c->sel_ticket) {
         TRY(dmalloc(c, &c->sel_ticket, TICKET_WORDS));
         HIPCHK(c, hipMemsetAsync(c->sel_ticket, 0, TICKET_WORDS * 4, c->stream));
@@ -350,21 +425,32 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->use_cand = false;
     c->table.cand_cs = nullptr;
     c->table.cand_list = nullptr;
-    if (!optv(c, "cand_argmax", 1) || !c->table.incand || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
-    const uint64_t words = incand_words(c->table.cap);
+    const bool dense = c->table.dense != nullptr;
+    if (!optv(c, "cand_argmax", 1) || (!dense && !c->table.incand) || !c->cand_state || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
+    const uint64_t words = dense ? 0 : incand_words(c->table.cap);
     const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 768));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
     CandState h{};
     for (int attempt = 0; attempt < 12; ++attempt) {
         unsigned long long margin = (unsigned long long)((double)best_count * c->cand_margin);
         if (margin < 1) margin = 1;
-        HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
+        if (!dense) HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
         h = CandState{best_count - std::min(margin, best_count - 1), 0u, 0u, 0u, 0u};
         HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         PairTable t = c->table;
         t.cand_list = c->cand;
-        CandParams P{t, c->tt.rec, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
-        hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+        t.cand_cs = c->cand_state;
+        t.cand_T = h.T;
+        if (dense) {  // only the rows that can hold a count >= T (their bounds are refreshed on the way)
+            TRY(dense_list_rows(c, c->st_host->n_tokens, h.T, 0));
+            if (c->n_scan_rows) {
+                DenseScanParams D{t, c->scan_rows, c->n_scan_rows, c->tt.rec, nullptr, c->st, (c->pending && c->st_host->c_is_new) ? c->st_host->c : EMPTY};
+                hipLaunchKernelGGL(k_dense_scan<true>, dim3(std::min<uint32_t>(c->n_scan_rows, 2048)), dim3(BLOCK), 0, c->stream, D);
+            }
+        } else {
+            CandParams P{t, c->tt.rec, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
+            hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&h, c->cand_state, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -541,7 +627,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
     if (!c->multi) return launch_count_local(c, t);
     // generic multi-GPU count: local table -> records -> all-gather -> sum into t
     PairTable lt{};
-    const uint64_t lcap = (uint64_t)t.cap;
+    const uint64_t lcap = t.dense ? std::max<uint64_t>(c->local_count_cap, 1ull << 20) : (uint64_t)t.cap;
     HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
     TRY(table_alloc(c, lt, lcap, &c->scratch64[9]));
     TRY(launch_count_local(c, lt));
@@ -552,6 +638,37 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
 
 // (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
 int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
+    if (want_dense(c)) {
+        // direct-indexed counts: zero the rows of the tokens that exist and count again (multi-GPU: through local tables and
+        // one exchange; a local table that is too small is the only thing that can fail here, and all ranks retry together)
+        TRY(state_pull(c));
+        const uint32_t n_tok = c->st_host->n_tokens;
+        if (!c->table.dense || c->table.dense_v < n_tok) {
+            table_free(c->table);
+            TRY(dense_alloc(c, c->table, std::min<uint32_t>(YB_MAX_TOKENS, n_tok + 1024)));
+        }
+        c->table_cap = tri_size(c->table.dense_v);
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            c->table.cand_cs = nullptr;
+            c->table.cand_list = nullptr;
+            HIPCHK(c, hipMemsetAsync(c->table.dense, 0, tri_size(n_tok) * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->table.rowmax, 0xFF, (size_t)n_tok * 8, c->stream));  // (unknown until a scan refreshes them)
+            HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, sizeof(uint32_t), c->stream));
+            c->local_count_cap = std::max<uint64_t>(c->local_count_cap, 1ull << 20);
+            TRY(launch_count(c, c->table, all_bytes));
+            TRY(state_pull(c));
+            unsigned long long bad = c->st_host->halt_req != 0 ? 1 : 0, any_bad = 0;
+            TRY(comm_max(c, bad, &any_bad));
+            if (!any_bad) {
+                c->stats.table_rebuilds++;
+                TRY(cand_attach(c));
+                return 0;
+            }
+            c->local_count_cap *= 4;
+        }
+        return fail(c, YABPE_E_CAPACITY, "local count table does not fit");
+    }
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
     bool shrunk = false;
     for (int attempt = 0; attempt < 16; ++attempt) {
@@ -795,6 +912,7 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->cand_state);
     dfree(c->sel_ticket);
     dfree(c->cand);
+    dfree(c->scan_rows);
     dfree(c->xsend);
     dfree(c->xrecv);
     dfree(c->xsmall);
@@ -1101,7 +1219,8 @@ static SelectParams select_params(yabpe_ctx *c, uint32_t rec_base, uint32_t n_pa
 // The selection as launches of its own (trainer.py:241-251, 296-300): exact argmax over the candidate list, or over the
 // whole table when there is no list, then stop rules and merged-token creation.
 static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
-    const uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64) : c->n_partials;
+    const uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64)
+                            : c->table.dense ? std::max(1u, std::min<uint32_t>(c->n_scan_rows, c->n_partials)) : c->n_partials;
     const SelectParams S = select_params(c, rec_base, n_part, c->blk_used);
     c->blk_used = 0;  // the selection folds and clears them; what follows counts the next merge's grids
     bool selected = false;
@@ -1110,6 +1229,9 @@ static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
         CandParams CP{c->table, c->tt.rec, c->partials, c->st, c->cand_state, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;
+    } else if (c->table.dense) {  // the rows the batch prologue listed (dense_list_rows): every row that may hold a pair
+        DenseScanParams D{c->table, c->scan_rows, c->n_scan_rows, c->tt.rec, c->partials, c->st, EMPTY};
+        hipLaunchKernelGGL(k_dense_scan<false>, dim3(n_part), dim3(BLOCK), 0, c->stream, D);
     } else {
         ArgmaxParams A{c->table, c->tt.rec, c->partials, c->st};
         hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
@@ -1287,9 +1409,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     if (out_n_merges) *out_n_merges = 0;
     TRY(state_pull(c));
     DevState *h = c->st_host;
-    if ((uint64_t)h->n_tokens + num_merges > YB_MAX_TOKENS)
-        return fail(c, YABPE_E_CAPACITY, "vocabulary of %llu tokens exceeds the u16 id space (max %u)",
-                    (unsigned long long)h->n_tokens + num_merges, (unsigned)YB_MAX_TOKENS);
+    // The u16 id space bounds the vocabulary at YB_MAX_TOKENS.  The reference has no such bound, and a job that asks for more
+    // merges than that usually stops long before (no pairs left, min_frequency): the request is clamped to one merge past
+    // the last id, and only if the loop really gets there with a pair still to merge does the selection stop it
+    // (HALT_VOCAB_FULL -> YABPE_E_CAPACITY below) -- reported, never silently truncated.
+    if ((uint64_t)h->n_tokens + num_merges > YB_MAX_TOKENS) num_merges = YB_MAX_TOKENS - h->n_tokens + 1;
     const uint32_t rec_base = h->iter;
     h->num_merges = rec_base + num_merges;
     h->min_freq = min_frequency;
@@ -1307,6 +1431,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     c->sig_valid = false;
     c->dense_mode = false;
     if (num_merges == 0) return YABPE_OK;
+    if (c->table.dense) {
+        // rows for the tokens this call can create: all of them up front when the corpus is large (it will use them, and a
+        // matrix that grows in steps copies itself each time); small jobs grow as they go (many stop long before the limit)
+        const uint32_t want = h->n_tokens + (c->tokens_initial >= (16ull << 20) ? num_merges : std::min<uint32_t>(num_merges, 1024u)) + 16u;
+        TRY(dense_ensure_rows(c, want));
+    }
 
     if (c->rec_cap < num_merges) {
         free_records(c);
@@ -1428,6 +1558,8 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         // i = merges whose selection has been launched.  Fused form: one launch applies merge i - 1 and selects merge i;
         // otherwise a merge is a selection launch followed by its apply launch(es).
         const bool fuse = can_fuse(c);
+        if (c->table.dense && !c->use_cand)  // the fallback argmax scans rows: list them once for the whole batch
+            TRY(dense_list_rows(c, h->n_tokens, 1, (batch_end > i ? batch_end - i : 0) + 2));
         if (c->pending && (!fuse || i >= num_merges)) {  // leave the fused form: the selected merge is applied on its own
             TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i - 1), false));
             c->pending = false;
@@ -1480,6 +1612,13 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;
                 continue;
             }
+            if (h->halt == HALT_MATRIX_ROWS) {  // (the net under the row growth between batches: nothing was selected)
+                h->halt = 0; h->halt_req = 0;
+                TRY(state_push(c));
+                TRY(dense_ensure_rows(c, h->n_tokens + 2 * check + 16));
+                i = h->iter - rec_base;
+                continue;
+            }
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
                               : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
                                                            : "device halt";
@@ -1494,7 +1633,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         // kept at 12-30 % load: a key that is not at its home slot costs the flush of every merge a dependent trip (the
         // 1 GiB job: 1.60 s at 50-70 % load, 1.42 s at 12-30 %), and the table is scanned only now and then (candidate
         // rebuilds).  Same decision on every rank.
-        if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
+        if (c->table.dense)  // rows for the tokens the next batches will create
+            TRY(dense_ensure_rows(c, h->n_tokens + 2 * check + 16));
+        else if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
             TRY(table_grow(c, std::max<uint64_t>(h->table_entries * (uint64_t)std::max<int64_t>(2, optv(c, "table_grow_x", 8)), 1ull << 16)));
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
@@ -1715,6 +1856,24 @@ int yabpe_verify_table(yabpe_ctx *c, uint64_t *out_mismatches) {
     if (!c->have_words) return fail(c, YABPE_E_INVALID, "no corpus loaded");
     PairTable scratch{};
     HIPCHK(c, hipMemsetAsync(&c->scratch64[4], 0, 16, c->stream));  // [4] entries, [5] mismatches
+    if (c->table.dense) {  // recount into a second matrix over the same tokens, compare entry by entry
+        TRY(state_pull(c));
+        const uint32_t n_tok = c->st_host->n_tokens;
+        TRY(dense_alloc(c, scratch, n_tok));
+        scratch.entries = &c->scratch64[4];
+        TRY(launch_count(c, scratch));
+        const unsigned long long n = tri_size(n_tok);
+        hipLaunchKernelGGL(k_dense_compare, dim3((uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, n / BLOCK))), dim3(BLOCK), 0, c->stream,
+                           c->table.dense, scratch.dense, n, &c->scratch64[5]);
+        HIPCHK(c, hipGetLastError());
+        unsigned long long mmd = 0;
+        HIPCHK(c, hipMemcpyAsync(&mmd, &c->scratch64[5], 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        table_free(scratch);
+        HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, 4, c->stream));
+        *out_mismatches = mmd;
+        return YABPE_OK;
+    }
     TRY(table_alloc(c, scratch, c->table_cap, &c->scratch64[4]));
     TRY(launch_count(c, scratch));
     uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / BLOCK));

@@ -40,7 +40,7 @@ constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined 
 constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
 constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
-enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
+enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5, HALT_MATRIX_ROWS = 6 };
 
 struct DevState {
     uint32_t iter;       // merges recorded so far
@@ -100,7 +100,23 @@ struct PairTable {
     DeltaRec *sink_rec;
     DeltaHdr *sink_hdr;
     uint32_t sink_cap;
+    // Direct-indexed form (the main table by default): dense != NULL -- one u64 count per POSSIBLE pair of the dense_v tokens
+    // the matrix has rows for, no keys, no probing, no inserts (keys / cnt / cap / incand are unused).  Pair (x, y) belongs
+    // to the row of its YOUNGER token o = max(x, y): row o holds the 2 (o + 1) pairs (o, j <= o) and (j < o, o), rows are
+    // stored one after the other (row o starts at o (o + 1)).  A merge only ever CREATES adjacencies with the token it has
+    // just made, so all the counts that go up in a merge lie in that one new row, and a row never grows after the merge
+    // that made its token: rowmax[o] (set by the selection, refreshed by scans) bounds it from above and lets scans skip rows.
+    // 288 GB of HBM is what makes this layout the natural one here: 8.3 GB for 32k merges, 34 GB at the u16 id limit.
+    unsigned long long *dense;
+    unsigned long long *rowmax;
+    uint32_t dense_v;
 };
+YB_HD unsigned long long tri_idx(uint32_t key) {
+    const unsigned long long x = key >> 16, y = key & 0xffffu;
+    return x >= y ? x * (x + 1ull) + y : y * (y + 1ull) + y + 1ull + x;
+}
+YB_HD unsigned long long tri_size(uint32_t v) { return (unsigned long long)v * ((unsigned long long)v + 1ull); } // entries of rows 0 .. v-1
+YB_HD uint32_t tri_key(uint32_t o, uint32_t j) { return j <= o ? ((o << 16) | j) : (((j - o - 1u) << 16) | o); } // entry j of row o
 // words of the `incand` bitmap of a table of `cap` slots
 YB_HD uint32_t incand_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
@@ -226,8 +242,33 @@ __device__ __forceinline__ void cand_note(const PairTable &t, uint32_t s, uint32
     else
         st_coherent(&t.cand_cs->overflow, 1u);
 }
+// the count of `key` (dense form), or of the slot an entry of the candidate list names
+__device__ __forceinline__ unsigned long long *pt_count_ptr(const PairTable &t, unsigned long long entry) {
+    return t.dense ? &t.dense[tri_idx((uint32_t)(entry >> 32))] : &t.cnt[(uint32_t)entry];
+}
+// dense form: count(key) += d.  A count that crosses the threshold of the candidate argmax on its way up joins the list
+// (exactly one adder sees the crossing; a pair that falls below and crosses again is listed twice, which is harmless).
+__device__ __forceinline__ void gt_bump_dense(const PairTable &t, uint32_t key, long long d) {
+    unsigned long long *p = &t.dense[tri_idx(key)];
+    if (d > 0 && t.cand_list) {
+        const unsigned long long old = atomicAdd(p, (unsigned long long)d), now = old + (unsigned long long)d;
+        if (old < t.cand_T && now >= t.cand_T && (long long)now > 0) {
+            const uint32_t idx = atomicAdd(&t.cand_cs->n, 1u);
+            if (idx < CAND_CAP)
+                st_coherent(&t.cand_list[idx], (unsigned long long)key << 32);
+            else
+                st_coherent(&t.cand_cs->overflow, 1u);
+        }
+    } else {
+        atomicAdd(p, (unsigned long long)d);
+    }
+}
 // cnt[s] += d
 __device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t key, long long d) {
+    if (t.dense) {
+        gt_bump_dense(t, key, d);
+        return;
+    }
     if (d > 0 && t.cand_list) {
         const unsigned long long old = atomicAdd(&t.cnt[s], (unsigned long long)d);
         cand_note(t, s, key, old + (unsigned long long)d);
@@ -245,6 +286,10 @@ __device__ __forceinline__ void sink_append(const PairTable &t, uint32_t key, lo
 __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t s, uint32_t *inserted) {
     if (t.sink_rec) {
         sink_append(t, key, d);
+        return;
+    }
+    if (t.dense) {
+        gt_bump_dense(t, key, d);
         return;
     }
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
@@ -266,7 +311,7 @@ __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, ui
     atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
 }
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
-    gt_add_from(t, st, key, d, t.sink_rec ? 0u : pt_home(t, key), inserted);
+    gt_add_from(t, st, key, d, (t.sink_rec || t.dense) ? 0u : pt_home(t, key), inserted);
 }
 
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
@@ -405,6 +450,16 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             if (v[q] == 0) continue;
             if (at < t.sink_cap) t.sink_rec[at] = DeltaRec{k[q], 0u, v[q]};
             ++at;
+        }
+        return;
+    }
+    if (t.dense) { // direct-indexed counts: every delta is ONE atomic, nothing to look up first
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = threadIdx.x + q * BLOCK;
+            const uint32_t key = g.keys[i];
+            const long long val = (long long)g.vals[i];
+            if (key != EMPTY && val != 0) gt_bump_dense(t, key, val);
         }
         return;
     }
@@ -1787,7 +1842,7 @@ __device__ __forceinline__ BestEx cand_list_best(const PairTable &t, const TokRe
             cn[k] = 0ull;
             if (i0 + (uint32_t)k * step < n) {
                 const uint32_t key = (uint32_t)(e[k] >> 32);
-                cn[k] = ld_coherent(&t.cnt[(uint32_t)e[k]]);
+                cn[k] = ld_coherent(pt_count_ptr(t, e[k]));
                 ld_rec_coherent(&rec[key >> 16], rl[k], lx[k], hx[k]);
                 ld_rec_coherent(&rec[key & 0xffffu], rr[k], ly[k], hy[k]);
             }
@@ -1878,7 +1933,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             cn[k] = 0ull;
-            if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(&P.table.cnt[(uint32_t)e[k]]);
+            if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(pt_count_ptr(P.table, e[k]));
         }
         if (n_list != 0xdeadbeefu) YB_SEL_STAMP(9); // (profile build: list length + entries have arrived, counts requested)
 #pragma unroll
@@ -1960,7 +2015,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         }
         // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
         // no replica can run out of probes on its own.
-        if (d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full
+        if (!P.table.dense && d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full
         d_sites += s_fold[0];
         d_live_slots -= s_fold[1];
         if (d_done | d_halt) {
@@ -2071,6 +2126,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         } else if (d_n_tokens >= YB_MAX_TOKENS) {
             st->halt = HALT_VOCAB_FULL;
             return;
+        } else if (P.table.dense && d_n_tokens >= P.table.dense_v) {
+            st->halt = HALT_MATRIX_ROWS; // (the host adds rows ahead of time; this is the net under it)
+            return;
         } else if ((unsigned long long)pu + L + 4ull > P.tt.pool_cap) {
             st->halt = HALT_POOL_FULL;
             return;
@@ -2092,7 +2150,14 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         P.rec_live_slots[ri] = d_live_slots;
         // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
         // set it here once instead of letting every workgroup subtract its share from one hot address
-        P.table.cnt[win.slot] = 0ull;
+        if (P.table.dense) {
+            P.table.dense[tri_idx(win.key)] = 0ull;
+            // every adjacency this merge creates contains cid: its row can gain at most the merged count per pair
+            const unsigned long long rm = is_new ? 0ull : P.table.rowmax[cid];
+            P.table.rowmax[cid] = rm > ~0ull - win.cnt ? ~0ull : rm + win.cnt;
+        } else {
+            P.table.cnt[win.slot] = 0ull;
+        }
         st->a = x;
         st->b = y;
         st->c = cid;
@@ -2637,6 +2702,77 @@ template <bool INLINE, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 4 workgroups per CU)
     if (!scan_skip_block<INLINE, FULL, WEIGHTED>(Q)) return;
     if constexpr (FULL) fused_select_tail(Q.F);
+}
+
+// ================================================================ scans of the direct-indexed count matrix
+// Only the rows the host lists (rowmax >= what the scan is looking for).  One workgroup per row at a time; a row is read as
+// consecutive u64 (coalesced).  REBUILD: every pair with count >= T goes on the candidate list and the row's exact maximum
+// replaces its bound.  !REBUILD: the argmax by (count, ranks) over the listed rows, one partial per workgroup (k_select
+// finishes) -- the fallback when no candidate list can prove the maximum (first merges, tiny counts).
+struct DenseScanParams {
+    PairTable table;
+    const uint32_t *rows;
+    uint32_t n_rows;
+    const TokRec *rec;
+    Best *partials; // [gridDim.x] (!REBUILD)
+    DevState *st;
+    uint32_t keep_row; // REBUILD: the token of a merge that is selected but not applied yet -- its row is still empty and
+                       // about to fill: its bound (set by the selection) must stand
+};
+template <bool REBUILD>
+__global__ __launch_bounds__(BLOCK) void k_dense_scan(DenseScanParams P) {
+    __shared__ unsigned long long s_rmax[WPB];
+    __shared__ Best s_b[WPB];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const unsigned long long T = REBUILD ? P.table.cand_T : 0ull;
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
+    if (!REBUILD && (P.st->done | P.st->halt)) return;
+    for (uint32_t r = blockIdx.x; r < P.n_rows; r += gridDim.x) {
+        const uint32_t o = P.rows[r], len = 2u * (o + 1u);
+        const unsigned long long *row = P.table.dense + (unsigned long long)o * (o + 1ull);
+        unsigned long long rmax = 0ull;
+        for (uint32_t j = threadIdx.x; j < len; j += BLOCK) {
+            const long long cn = (long long)row[j];
+            if (cn <= 0) continue;
+            const uint32_t key = tri_key(o, j);
+            if (REBUILD) {
+                rmax = (unsigned long long)cn > rmax ? (unsigned long long)cn : rmax;
+                if ((unsigned long long)cn >= T) {
+                    const uint32_t idx = atomicAdd(&P.table.cand_cs->n, 1u);
+                    if (idx < CAND_CAP) P.table.cand_list[idx] = (unsigned long long)key << 32; else P.table.cand_cs->overflow = 1u;
+                }
+            } else if ((unsigned long long)cn >= best.cnt) {
+                const Best e{(unsigned long long)cn, (P.rec[key >> 16].rank << 16) | P.rec[key & 0xffffu].rank, key, 0u, 0u};
+                if (best_gt(e, best)) best = e;
+            }
+        }
+        if (REBUILD) {
+            rmax = best_wave_reduce(Best{rmax, 0u, 0u, 0u, 0u}).cnt;
+            if (lane == 0) s_rmax[wib] = rmax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < WPB; ++w) rmax = s_rmax[w] > rmax ? s_rmax[w] : rmax;
+                if (o != P.keep_row) P.table.rowmax[o] = rmax;
+            }
+            __syncthreads();
+        }
+    }
+    if (!REBUILD) {
+        best = best_wave_reduce(best);
+        if (lane == 0) s_b[wib] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < WPB; ++i)
+                if (best_gt(s_b[i], best)) best = s_b[i];
+            P.partials[blockIdx.x] = best;
+        }
+    }
+}
+// debug: two matrices over the same tokens, entry by entry
+__global__ __launch_bounds__(BLOCK) void k_dense_compare(const unsigned long long *a, const unsigned long long *b, unsigned long long n, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) bad += a[i] != b[i];
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // ================================================================ table growth: re-insert live entries (count != 0)

@@ -145,7 +145,7 @@ class BBPETrainer:
                 return empty
             ctx.set_vocab(base)
             ctx.load_words_ptr(dev_text, dev_off, n_words, dedup=os.environ.get("YABPE_LAYOUT", "dedup") != "flat")
-            left, right, merged, _count = ctx.train(num_merges, int(self.config.min_frequency))
+            left, right, merged, _count = ctx.train(num_merges, max(0, int(self.config.min_frequency)))  # (<= 0: merge to exhaustion, as the reference does)
             self.last_stats = ctx.stats()
         vocab, merges = self._decode_merges(base, left, right, merged)
         self._vocab = vocab
@@ -271,6 +271,6 @@ class BBPETrainer:
         with _native.Context() as ctx:
             ctx.set_vocab(base)
             ctx.load_words(flat, off, freq)
-            left, right, merged, _count = ctx.train(num_merges, int(self.config.min_frequency))
+            left, right, merged, _count = ctx.train(num_merges, max(0, int(self.config.min_frequency)))  # (<= 0: merge to exhaustion, as the reference does)
             self.last_stats = ctx.stats()
         return self._decode_merges(base, left, right, merged)
