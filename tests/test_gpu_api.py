@@ -181,3 +181,92 @@ class TestTrainIntegration:
         t = BBPETrainer(BBPETrainerConfig(vocab_size=275, min_frequency=1, max_workers=1))
         words = [bytes(s) for s in t._preprocess_corpus([DATA / "unicode.txt"])]
         assert model.merges == _o.merge_loop(words, 275, 1, ["[PAD]", "[UNK]", "[BOS]", "[EOS]"])[1]
+
+
+class TestTrainOrchestration:
+    """reference tests/test_trainer.py:354-483, restated (train() through the device path)."""
+
+    @pytest.mark.parametrize("files,vocab_size,mf", [(["simple.txt"], 270, 2), (["simple.txt", "unicode.txt"], 280, 2)])
+    def test_model_shape(self, files, vocab_size, mf):
+        cfg = BBPETrainerConfig(vocab_size=vocab_size, min_frequency=mf, max_workers=1)
+        model = BBPETrainer(cfg).train([DATA / f for f in files])
+        assert isinstance(model, BBPEModel) and 260 <= len(model.vocab) <= vocab_size
+        assert all(isinstance(k, bytes) and isinstance(v, int) for k, v in model.vocab.items())
+        assert isinstance(model.merges, list) and all(isinstance(m, tuple) and len(m) == 2 and isinstance(m[0], bytes) and isinstance(m[1], bytes) for m in model.merges)
+        assert model.special_tokens == list(cfg.special_tokens) and all(isinstance(t, str) for t in model.special_tokens)
+
+    def test_empty_corpus_gives_the_base_vocab(self):
+        model = BBPETrainer(BBPETrainerConfig(vocab_size=300, min_frequency=2, max_workers=1)).train([DATA / "empty.txt"])
+        assert len(model.vocab) == 260 and model.merges == []
+
+    def test_vocab_size_limit_and_min_frequency(self):
+        model = BBPETrainer(BBPETrainerConfig(vocab_size=265, min_frequency=1, max_workers=1)).train([DATA / "simple.txt"])
+        assert len(model.vocab) <= 265
+        model = BBPETrainer(BBPETrainerConfig(vocab_size=300, min_frequency=10, max_workers=1)).train([DATA / "simple.txt"])
+        assert len(model.merges) < 5  # simple.txt is 12 bytes: nothing occurs ten times
+
+    def test_trainer_state_and_base_tokens(self):
+        cfg = BBPETrainerConfig(vocab_size=280, min_frequency=1, max_workers=2)
+        trainer = BBPETrainer(cfg)
+        model = trainer.train([DATA / "multiline.txt"])
+        assert len(trainer._vocab) >= 260 and isinstance(trainer._merges, list) and trainer._merges == model.merges
+        assert all(bytes([i]) in model.vocab for i in range(256))
+        assert all(s.encode("utf-8") in model.vocab for s in cfg.special_tokens)
+        words = [bytes(s) for s in trainer._preprocess_corpus([DATA / "multiline.txt"])]  # the oracle agrees with the whole train()
+        assert (model.vocab, model.merges) == oracle.merge_loop(words, 280, 1, list(cfg.special_tokens))
+
+    def test_no_files_and_missing_file(self):
+        with pytest.raises(ValueError, match="At least one file"):
+            BBPETrainer(BBPETrainerConfig()).train([])
+        with pytest.raises(FileNotFoundError):
+            BBPETrainer(BBPETrainerConfig()).train([DATA / "does_not_exist.txt"])
+
+
+class TestModelPersistence:
+    """reference tests/test_trainer.py:486-604, restated."""
+
+    def test_save_layout_and_contents(self, tmp_path):
+        trainer = BBPETrainer(BBPETrainerConfig(vocab_size=270, min_frequency=1, max_workers=1))
+        trainer.train([DATA / "simple.txt"])
+        out = tmp_path / "model"
+        trainer.save(out)
+        assert out.is_dir()
+        vocab = json.loads((out / "vocab.json").read_text(encoding="utf-8"))
+        assert isinstance(vocab, dict) and len(vocab) >= 260 and all(t in vocab for t in ("[PAD]", "[UNK]", "[BOS]", "[EOS]"))
+        lines = [ln for ln in (out / "merges.txt").read_text(encoding="utf-8").splitlines() if ln.strip()]
+        assert lines and all(1 <= len(ln.strip().split(maxsplit=1)) <= 2 for ln in lines)
+        assert any(len(ln.strip().split(maxsplit=1)) == 2 for ln in lines)
+        assert json.loads((out / "special_tokens.json").read_text(encoding="utf-8")) == ["[PAD]", "[UNK]", "[BOS]", "[EOS]"]
+
+    def test_save_without_training(self, tmp_path):
+        with pytest.raises(ValueError, match="not been trained"):
+            BBPETrainer(BBPETrainerConfig()).save(tmp_path / "model")
+
+
+class TestTokenizerOnTrainedModel:
+    """reference tests/test_tokenizer.py:135-522 on a model the GPU trained: train -> save -> from_file -> round trips."""
+
+    @pytest.fixture
+    def tok(self, tmp_path):
+        from yet_another_bpe.tokenizer import BBPETokenizer
+
+        trainer = BBPETrainer(BBPETrainerConfig(vocab_size=300, min_frequency=1, max_workers=1))
+        trainer.train([DATA / "multiline.txt"])
+        trainer.save(tmp_path / "model")
+        return BBPETokenizer.from_file(tmp_path / "model")
+
+    def test_round_trips_and_id_range(self, tok):
+        for text in ["", "a", "Hello, world!", "你好世界 Hello 안녕하세요", "Line 1\nLine 2\nLine 3", "Hello   world\t\ttabs", "Hello \U0001f44b World \U0001f30d", "Hello world! " * 200]:
+            ids = tok.encode(text)
+            assert all(0 <= i < tok.vocab_size for i in ids) and tok.decode(ids) == text
+        assert tok.decode_batch(tok.encode_batch(["Hello!", "World!", "Test 123"])) == ["Hello!", "World!", "Test 123"]
+
+    def test_special_token_round_trip(self, tmp_path):
+        from yet_another_bpe.tokenizer import BBPETokenizer
+
+        trainer = BBPETrainer(BBPETrainerConfig(vocab_size=270, min_frequency=1, max_workers=1, special_tokens=["<|endoftext|>"]))
+        trainer.train([DATA / "simple.txt"])
+        trainer.save(tmp_path / "m")
+        tok = BBPETokenizer.from_file(tmp_path / "m")
+        ids = tok.encode("Hello<|endoftext|>World")
+        assert tok.get_vocab()["<|endoftext|>"] in ids and tok.decode(ids) == "Hello<|endoftext|>World"

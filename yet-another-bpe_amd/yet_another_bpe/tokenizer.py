@@ -59,6 +59,24 @@ class BBPETokenizer:
                 specials = list(json.load(f))
         return cls(vocab=vocab, merges=merges, special_tokens=specials)
 
+    @classmethod
+    def from_file_lossless(cls, model_dir: str | Path) -> "BBPETokenizer":
+        """Loads what BBPETrainer.save_lossless wrote (hex files): every token and merge exactly as trained."""
+        d = Path(model_dir)
+        with open(d / "vocab.hex.json", encoding="ascii") as f:
+            vocab = {bytes.fromhex(k): v for k, v in json.load(f).items()}
+        merges: list[tuple[bytes, bytes]] = []
+        with open(d / "merges.hex", encoding="ascii") as f:
+            for line in f:
+                left, _, right = line.strip().partition(" ")
+                if left or right:
+                    merges.append((bytes.fromhex(left), bytes.fromhex(right)))
+        specials: list[str] = []
+        if (d / "special_tokens.json").exists():
+            with open(d / "special_tokens.json", encoding="utf-8") as f:
+                specials = list(json.load(f))
+        return cls(vocab=vocab, merges=merges, special_tokens=specials)
+
     # ------------------------------------------------------------------ encode
     def _word_ids_uncached(self, word: str) -> tuple[int, ...]:
         data = word.encode("utf-8")

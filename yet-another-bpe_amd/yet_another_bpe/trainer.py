@@ -176,6 +176,24 @@ class BBPETrainer:
         with open(out / "special_tokens.json", "w", encoding="utf-8") as f:
             json.dump(list(self.config.special_tokens), f, ensure_ascii=False, indent=2)
 
+    def save_lossless(self, output_dir: str | Path) -> None:
+        """The same model in a format that survives a reload byte for byte: `vocab.hex.json` ({token hex: id}),
+        `merges.hex` (one `left_hex right_hex` line per merge, the serialisation of the golden files) and
+        special_tokens.json.  The reference's own format (save()) loses every merge whose LEFT token contains a space --
+        its loader splits each line at the first space (tokenizer.py:137) -- and every token with a line break; it is kept
+        as it is for compatibility, this one is offered next to it (BBPETokenizer.from_file_lossless)."""
+        if not self._vocab:
+            raise ValueError("Model has not been trained yet. Call train() first.")
+        out = Path(output_dir)
+        out.mkdir(parents=True, exist_ok=True)
+        with open(out / "vocab.hex.json", "w", encoding="ascii") as f:
+            json.dump({tok.hex(): idx for tok, idx in self._vocab.items()}, f, indent=0)
+        with open(out / "merges.hex", "w", encoding="ascii") as f:
+            for left, right in self._merges:
+                f.write(f"{left.hex()} {right.hex()}\n")
+        with open(out / "special_tokens.json", "w", encoding="utf-8") as f:
+            json.dump(list(self.config.special_tokens), f, ensure_ascii=False, indent=2)
+
     # ------------------------------------------------------------------ base vocab (trainer.py:119-134)
     def _base_tokens(self) -> list[bytes]:
         toks = [bytes([b]) for b in range(256)]
