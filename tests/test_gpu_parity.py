@@ -216,3 +216,32 @@ def test_vocab_id_space_limit_is_reported():
         with pytest.raises(_native.YabpeError) as e:
             ctx.train(70_000, 1)
         assert e.value.code == -4 and "id space exhausted" in str(e.value)
+
+
+def test_many_long_words_filtered_by_signature():
+    """100,000 words longer than the tile path's limit next to ordinary ones: the long-word launch tests one signature
+    word per long word and rewrites only the words that may hold the pair (SURVEY 8f / VERDICT r1 #5); with and without
+    the filter, and pooled, the result is the oracle's.  The time per merge of both forms goes to stdout (-s)."""
+    import time
+
+    from yet_another_bpe import _native
+
+    rng = np.random.default_rng(17)
+    n_long, n_short = 100_000, 60_000
+    lens = np.concatenate([rng.integers(64, 91, size=n_long), rng.integers(2, 12, size=n_short)]).astype(np.uint64)
+    rng.shuffle(lens)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    flat = rng.choice(np.frombuffer(b"abcdefghij  ", dtype=np.uint8), size=int(off[-1])).astype(np.uint8)
+    base = helpers.base_tokens(SP)
+    exp_vocab, exp_merges = oracle.train_flat(flat, off, 257 + 300, 1, SP)
+    took = {}
+    for opts in ({"long_sig": 1}, {"long_sig": 0}, {"long_sig": 1, "fused": 0}):
+        t0 = time.perf_counter()
+        v, m, st = _native.train_words(flat, off, None, base, 300, 1, options={"verify": 1, **opts}, want_stats=True)
+        took[tuple(sorted(opts.items()))] = (time.perf_counter() - t0, st["train_ms"])
+        assert (v, m) == (exp_vocab, exp_merges), opts
+        assert st["n_long_words"] == n_long
+    print("long words: train_ms per merge", {k: round(v[1] * 1000 / 300, 1) for k, v in took.items()}, "us")
+    v, m = _native.train_words(flat, off, None, base, 300, 1, dedup=True, options={"verify": 1})
+    assert (v, m) == (exp_vocab, exp_merges)

@@ -111,6 +111,8 @@ struct yabpe_ctx {
     // long words
     uint32_t n_long = 0;
     uint16_t *long_tok = nullptr;
+    unsigned long long *long_sig = nullptr;  // one blocked-Bloom signature per long word (k_apply_long launches only what may hold the pair)
+    uint32_t long_sig_stride = 0;
     unsigned long long *long_off = nullptr;
     uint32_t *long_len = nullptr, *long_freq = nullptr;
     uint64_t long_tokens = 0;
@@ -566,7 +568,7 @@ int launch_count_local(yabpe_ctx *c, PairTable t) {
         HIPCHK(c, hipGetLastError());
     }
     if (c->n_long) {
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st};
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st, nullptr, 0u};
         hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
         HIPCHK(c, hipGetLastError());
     }
@@ -602,7 +604,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
         dfree(dense);
         if (c->n_long) {  // long words of this rank (bytes too) -- their pairs go through the generic exchange
             if (!c->multi) {
-                LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st};
+                LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, t, c->st, nullptr, 0u};
                 hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
                 HIPCHK(c, hipGetLastError());
             }
@@ -616,7 +618,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
         HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
         TRY(table_alloc(c, lt, 1ull << 18, &c->scratch64[9]));
         if (c->n_long) {
-            LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, lt, c->st};
+            LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, lt, c->st, nullptr, 0u};
             hipLaunchKernelGGL(k_count_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
             HIPCHK(c, hipGetLastError());
         }
@@ -755,7 +757,8 @@ void free_corpus(yabpe_ctx *c) {
     dfree(c->tiles); dfree(c->tiles_alt); dfree(c->tile_len); dfree(c->tile_len_alt);
     dfree(c->tile_wbase); dfree(c->tile_wbase_alt); dfree(c->wfreq); dfree(c->sig);
     c->sig = nullptr; c->sig_stride = 0;
-    dfree(c->long_tok); dfree(c->long_off); dfree(c->long_len); dfree(c->long_freq);
+    dfree(c->long_tok); dfree(c->long_off); dfree(c->long_len); dfree(c->long_freq); dfree(c->long_sig);
+    c->long_sig = nullptr; c->long_sig_stride = 0;
     c->tiles = c->tiles_alt = nullptr;
     c->tile_len = c->tile_len_alt = c->tile_wbase = c->tile_wbase_alt = c->wfreq = nullptr;
     c->long_tok = nullptr; c->long_off = nullptr; c->long_len = c->long_freq = nullptr;
@@ -1138,6 +1141,13 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         LoadLongParams L{d_bytes, d_off, d_freq, d_long_word, c->long_off, c->long_tok, c->long_len, c->long_freq, c->n_long};
         hipLaunchKernelGGL(k_load_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
         HIPCHK(c, hipGetLastError());
+        if (optv(c, "long_sig", 1)) {  // signatures: a merge whose pair is in no long word then costs 8 bytes per long word
+            c->long_sig_stride = (c->n_long + 31u) & ~31u;
+            TRY(dmalloc(c, &c->long_sig, (uint64_t)SIG_ROWS * c->long_sig_stride));
+            LongParams S{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, PairTable{}, c->st, c->long_sig, c->long_sig_stride};
+            hipLaunchKernelGGL(k_build_sig_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, S);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dfree(d_long_word);
@@ -1274,8 +1284,8 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
     if (fuse_kernel && c->n_long) {  // the long words first: the fused launch must be the last one to touch the table
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
-        hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
+        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, L);
     }
     // the fused selection folds the per-workgroup counters of THIS launch too: it must know the larger grid
     auto fuse_params = [&](uint32_t grid_now) {
@@ -1377,8 +1387,8 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
     if (!fuse_kernel && c->n_long) {
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st};
-        hipLaunchKernelGGL(k_apply_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
+        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
+        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, L);
     }
     if (c->multi) {
         // Per merge: the apply launch above left this rank's updates as [header | records] in its send buffer (the

@@ -1561,6 +1561,8 @@ struct LongParams {
     uint32_t n_long;
     PairTable out;
     DevState *st;
+    unsigned long long *sig; // per-word signatures, same blocked Bloom filter and layout as the tiles' (sig[row * stride + word]); may be NULL
+    uint32_t sig_stride;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_count_long(LongParams P) {
@@ -1572,22 +1574,57 @@ __global__ __launch_bounds__(BLOCK) void k_count_long(LongParams P) {
     for (uint32_t p = threadIdx.x; p + 1 < len; p += BLOCK) gt_add(P.out, P.st, yb_pairkey(t[p], t[p + 1]), w);
 }
 
+// signatures of the long words (at load): one workgroup per word
+__global__ __launch_bounds__(BLOCK) void k_build_sig_long(LongParams P) {
+    __shared__ unsigned long long s_sig[SIG_ROWS];
+    const uint32_t i = blockIdx.x;
+    if (i >= P.n_long) return;
+    for (int w = threadIdx.x; w < SIG_ROWS; w += BLOCK) s_sig[w] = 0ull;
+    __syncthreads();
+    const uint16_t *t = P.tok + P.off[i];
+    const uint32_t len = P.len[i];
+    for (uint32_t p = threadIdx.x; p + 1 < len; p += BLOCK) {
+        const SigHash H = sig_hash(yb_pairkey(t[p], t[p + 1]));
+        atomicOr(&s_sig[H.row], H.mask);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < SIG_ROWS; w += BLOCK) P.sig[(size_t)w * P.sig_stride + i] = s_sig[w];
+}
+
+// The merge applied to the long words.  A workgroup takes BLOCK consecutive words: one thread tests one word's signature
+// (ONE 8-byte load per word -- a merge whose pair occurs in no long word costs a launch of n_long / 256 workgroups that
+// read 8 bytes per word and leave), the words that pass are rewritten one after the other by the whole workgroup
+// (sequential greedy rewrite in chunks, thread 0 carries the state across chunks; the pairs it creates set their bits).
 __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     __shared__ uint16_t s_in[LONG_CH + 4];
     __shared__ uint16_t s_o[LONG_CH];
-    __shared__ uint32_t s_j, s_o_pos, s_adv, s_nout;
+    __shared__ uint32_t s_j, s_o_pos, s_adv, s_nout, s_nhit;
+    __shared__ uint32_t s_hit[BLOCK];
     DevState *st = P.st;
     if (st->done | st->halt) return;
-    const uint32_t i = blockIdx.x;
-    if (i >= P.n_long) return;
     const uint32_t a = st->a, b = st->b, c = st->c;
     const uint32_t self = yb_pairkey(a, b);
+    if (threadIdx.x == 0) s_nhit = 0;
+    __syncthreads();
+    {
+        const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+        bool maybe = i < P.n_long;
+        if (maybe && P.sig) {
+            const SigHash H = sig_hash(self);
+            maybe = (P.sig[(size_t)H.row * P.sig_stride + i] & H.mask) == H.mask;
+        }
+        if (maybe) s_hit[atomicAdd(&s_nhit, 1u)] = i;
+    }
+    __syncthreads();
+    const uint32_t n_hit = s_nhit;
+    for (uint32_t hidx = 0; hidx < n_hit; ++hidx) {
+    const uint32_t i = s_hit[hidx];
     uint16_t *t = P.tok + P.off[i];
     const uint32_t len = P.len[i];
     const long long w = P.freq ? (long long)P.freq[i] : 1;
     int any = 0;
     for (uint32_t p = threadIdx.x; p + 1 < len; p += BLOCK) any |= (t[p] == a) & (t[p + 1] == b);
-    if (!__syncthreads_or(any)) return;
+    if (!__syncthreads_or(any)) continue;
 
     if (threadIdx.x == 0) {
         s_j = 0;
@@ -1612,12 +1649,14 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
                     if (have_prev) {
                         if (yb_pairkey(prev_old, a) != self) gt_add(P.out, st, yb_pairkey(prev_old, a), -w);
                         gt_add(P.out, st, yb_pairkey(prev_new, c), +w);
+                        if (P.sig) sig_set_pair(P.sig, P.sig_stride, i, yb_pairkey(prev_new, c));
                     }
                     if (j + q + 2 < len) {
                         bool next_site = (j + q + 3 < len) && s_in[q + 2] == a && s_in[q + 3] == b;
                         if (!next_site) {
                             if (yb_pairkey(b, s_in[q + 2]) != self) gt_add(P.out, st, yb_pairkey(b, s_in[q + 2]), -w);
                             gt_add(P.out, st, yb_pairkey(c, s_in[q + 2]), +w);
+                            if (P.sig) sig_set_pair(P.sig, P.sig_stride, i, yb_pairkey(c, s_in[q + 2]));
                         }
                     }
                     s_o[no++] = (uint16_t)c;
@@ -1650,6 +1689,8 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     if (threadIdx.x == 0) {
         P.len[i] = s_o_pos;
         if (sites) atomicAdd(&st->sites, sites);
+    }
+    __syncthreads();
     }
 }
 
