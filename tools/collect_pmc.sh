@@ -1,33 +1,38 @@
 #!/bin/bash
-# HBM traffic of k_scan from PMC counters, as MI355X_MICROARCH.md prescribes: separate passes for FETCH_SIZE and
-# WRITE_SIZE (they do not fit one pass), --pmc never combined with trace options.  Run on the GPU box:
-#   bash tools/collect_pmc.sh [extra bench.py args]   -> gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}/..., summary printed as JSON
+# HBM traffic of the streaming-phase kernel (fused k_apply) from PMC counters, as MI355X_MICROARCH.md prescribes: separate
+# passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), --pmc never combined with trace options.  On the GPU box:
+#   bash tools/collect_pmc.sh   -> gpurun_out/pmc/summary.json (printed): mean bytes per launch over the first 64 launches
+# of k_apply<false> of the config-3 job, next to the algorithmic and actual stream bytes of the same launches.
 set -e
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc
 rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex "k_scan" --output-format csv -d $OUT/$C -- \
-    python3 bench.py --no-cpu-baseline --no-dedup-line --no-pretok-line --merges 2500 --roofline-merges 2500 "$@" > $OUT/bench_$C.json 2> $OUT/$C.err
+  rocprofv3 --pmc $C --kernel-include-regex "k_apply" --output-format csv -d $OUT/$C -- \
+    python3 $ROOT/tools/quick_job.py --merges 64 --runs 1 --sample 1 --dump-iter $OUT/iter_$C.json > $OUT/$C.log 2>&1
 done
+cd $ROOT
 python3 - <<'PY'
 import csv, glob, json
 def load(c):
-    f = glob.glob(f"gpurun_out/pmc/{c}/*/*counter_collection.csv")[0]
-    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("yb::k_scan(") and r["Counter_Name"] == c]
+    f = glob.glob(f"gpurun_out/pmc/{c}/**/*counter_collection.csv", recursive=True)[0]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_apply<" in r["Kernel_Name"] and r["Counter_Name"] == c]
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
-n_all = len(f)
-f = [x for x in f if x > 64.0]   # launches after the stop flag do nothing (< 1 us, no traffic): not part of the average,
-w = w[:len(f)] if len(w) >= len(f) else w   # as they are not part of bench.py's timed average either
-rf = json.load(open("gpurun_out/pmc/bench_FETCH_SIZE.json"))["roofline"]  # k_scan of the auxiliary pass
-mf, mw = sum(f) / len(f), sum(w) / len(w)
+it = json.load(open("gpurun_out/pmc/iter_FETCH_SIZE.json"))
+n = min(len(f), len(w), len(it["algo_bytes"]))
+f = [x for x in f if x > 64.0]  # launches behind a stop flag (the rest of a batch after a halt) do nothing: not merges
+w = [x for x in w if x > 64.0]
+n = min(len(f), len(w), len(it["algo_bytes"]))
+mf, mw = sum(f[:n]) / n, sum(w[:n]) / n
 traffic = 2 * mf * 1024 + mw * 1024
-out = {"kernel": "yb::k_scan", "dispatches": len(f), "dispatches_incl_noop": n_all, "mean_FETCH_SIZE_KiB": mf, "mean_WRITE_SIZE_KiB": mw,
-       "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2; unit KiB -> x1024",
-       "traffic_bytes_per_launch": traffic, "algo_bytes_per_launch_same_run": rf["algo_bytes_per_launch"],
-       "actual_stream_bytes_per_launch_same_run": rf["actual_stream_bytes_per_launch"],
-       "traffic_over_actual": traffic / rf["actual_stream_bytes_per_launch"], "traffic_over_algorithmic": traffic / rf["algo_bytes_per_launch"]}
+algo, actual = sum(it["algo_bytes"][:n]) / n, sum(it["actual_bytes"][:n]) / n
+out = {"kernel": "yb::k_apply<false> (fused per-merge launch of the streaming phase)", "dispatches": n, "mean_FETCH_SIZE_KiB": mf, "mean_WRITE_SIZE_KiB": mw,
+       "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2; unit KiB -> x1024; WRITE_SIZE exact for 16-B stores",
+       "traffic_bytes_per_launch": traffic, "algo_bytes_per_launch": algo, "actual_stream_bytes_per_launch": actual,
+       "traffic_over_actual": traffic / actual, "traffic_over_algorithmic": traffic / algo,
+       "command": "tools/collect_pmc.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE) --kernel-include-regex k_apply --output-format csv -- python3 tools/quick_job.py --merges 64 --runs 1 (the first 64 merges of the 1 GiB config-3 job: every launch is the fused k_apply)"}
 json.dump(out, open("gpurun_out/pmc/summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-rm -f gpurun_out/pmc/*/*/*counter_collection.csv   # tens of MB; the summary is what gets committed
+rm -rf gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE

@@ -14,6 +14,7 @@ ap.add_argument("--sample", type=int, default=8)
 ap.add_argument("--runs", type=int, default=2)
 ap.add_argument("--dedup", action="store_true")
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--dump-iter", default="", help="write per-merge algorithmic / actual stream bytes of the last run (JSON)")
 a = ap.parse_args()
 spec = synth.SynthSpec.config3(a.mib << 20)
 base = [bytes([b]) for b in range(256)] + [b"<|endoftext|>"]
@@ -32,6 +33,7 @@ with _native.Context() as g:
             wall = time.perf_counter() - t0
             st = ctx.stats()
             it, us, scan = ctx.event_log()
+            sites, live = ctx.iter_log()
         print(f"run {run}: {len(left)} merges, wall {wall*1e3:.1f} ms, train_ms {st['train_ms']:.1f}, {len(left)/wall:.0f} merges/s | fused {st['fused_launches']} "
               f"cand_rebuilds {st['cand_rebuilds']} rescans {st['cand_rescans']} retiles {st['retiles']} table_rebuilds {st['table_rebuilds']} cap {st['table_capacity']} entries {st['table_entries']}", flush=True)
 if len(it):
@@ -46,3 +48,12 @@ if len(it):
             tot += est
             print(f"  merges {lo:6d}-{hi:6d}: sampled {m.sum():5d}  apply+select avg {us[m].mean():8.1f} us  p50 {np.median(us[m]):8.1f}  max {us[m].max():8.1f}  => ~{est:7.1f} ms")
     print(f"  sum of segment estimates {tot:.1f} ms (events add ~4-5 us per sampled launch)")
+
+if a.dump_iter:
+    import json
+    T, algo, actual = st["tokens_initial"], [], []
+    for k in range(len(left)):
+        algo.append(int(2 * (T + st["n_words_input"])))
+        actual.append(int(2 * int(live[k]) + 4 * st["n_tiles"]))
+        T -= int(sites[k])
+    json.dump({"algo_bytes": algo, "actual_bytes": actual}, open(a.dump_iter, "w"))
