@@ -1,11 +1,12 @@
 // yabpe.hip -- C ABI (include/yabpe.h) over the HIP kernels in yabpe_kernels.h / yabpe_aux_kernels.h.
 // Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC yabpe.hip -o libyabpe.so
 //
-// Host control flow of yabpe_train (reference trainer.py:238-300): per merge the host enqueues
-//   k_argmax_partial -> k_select -> k_rank_update -> k_apply (+ k_apply_long)
-// on one stream with NO host round trip; every kernel reads the current merge / stop flags from DevState
-// in HBM.  The host looks at DevState every `check_interval` merges to stop early (done), to service a
-// halt (grow + recount the pair table) and to retile the shrinking token stream.
+// Host control flow of yabpe_train (reference trainer.py:238-300): per merge the host enqueues ONE launch on one stream
+// with NO host round trip -- k_apply (streaming phase) or k_scan_skip (sparse phase) applies the merge that DevState names
+// and its last workgroup selects the next one (fused_select_tail); every kernel reads the current merge / stop flags from
+// DevState in HBM.  The host looks at DevState every `check_interval` merges to stop early (done), to service a halt, to
+// grow the pair table, to refresh signatures / the candidate list and to retile the shrinking token stream.
+// Multi-GPU: apply launch (updates leave as records) -> one all-gather -> k_delta_apply (+ the selection).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is dlopen()ed when yabpe_comm_* is first used

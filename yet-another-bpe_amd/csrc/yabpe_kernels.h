@@ -7,12 +7,14 @@
 //                 straddle tiles, every word ends with SEP, PAD fills lead/tail.  tile_len[t] = live slots.
 //   pair table    open-addressing hash in HBM: keys u32 (left<<16|right), counts i64, updated with
 //                 device-scope atomics; per-workgroup LDS hash aggregates deltas first.
-//   k_apply       THE hot kernel: one coalesced read of the live token stream per merge (16 B per lane),
-//                 match (a,b) on packed dwords, and only in tiles that contain a site: rewrite + in-tile
-//                 compaction + pair-count deltas (tile_logic.h).  HBM-bound; no MFMA (integer indexing work).
-//   k_argmax_*    max over the table by (count, lexrank[left], lexrank[right])  (trainer.py:246)
-//   k_select      stop rules, merged-token creation / byte-string identity (trainer.py:241-251, 296-300)
-//   k_rank_update keeps lexrank[] = rank of every token's bytes in Python bytes order
+//   k_apply       streaming phase: one coalesced read of the live token stream per merge (16 B per lane), match (a,b) on
+//                 packed dwords, tiles with sites rewritten + compacted in place, pair-count deltas (tile_logic.h).
+//   k_scan_skip   sparse phase: a tile-level skip index (blocked Bloom signatures) finds the ~1 % of the tiles that may hold
+//                 the pair; only those are read and rewritten.
+//   select_body   the next merge: exact argmax over a candidate list by (count, lexrank[left], lexrank[right])
+//                 (trainer.py:246), stop rules, merged-token creation / byte-string identity (trainer.py:241-251, 296-300);
+//                 run by the LAST workgroup of the launch that applied the previous merge (fused_select_tail).
+//   rank blocks   extra workgroups of every launch keep lexrank[] = rank of every token's bytes in Python bytes order
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
