@@ -1370,7 +1370,10 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     };
     if (c->n_tiles) {
         ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats,
-                      c->split_mode ? c->sig : nullptr, c->sig_stride, (uint32_t)optv(c, "cas_first", 0)};  // signatures are maintained in the split form only
+                      c->split_mode ? c->sig : nullptr, c->sig_stride, (uint32_t)optv(c, "cas_first", 0),
+                      // a sparse merge leaves a workgroup a few dozen deltas: a quarter of the aggregator is plenty (less to
+                      // initialise and to flush); the count of the LAST batch's merge bounds this batch's (it never rises)
+                      (uint32_t)(optv(c, "agg_small", 1) && c->split_mode && !c->weighted && c->st_host->best_count * 4 < 48ull * std::max<uint32_t>(1u, c->n_cu * 3) ? AGG_N / 4 - 1 : AGG_N - 1)};  // signatures are maintained in the split form only
         if (!c->split_mode) {
             const FuseParams F = fuse_params(apply_grid);
             c->blk_used = std::max(c->blk_used, apply_grid);

@@ -322,11 +322,12 @@ template <class V>
 struct Agg {
     uint32_t *keys;
     V *vals;
+    uint32_t mask; // entries in use - 1 (AGG_N - 1, or fewer for a merge with few sites: less to initialise and to flush)
 };
 
 template <class V>
 __device__ __forceinline__ void agg_init(Agg<V> g) {
-    for (int i = threadIdx.x; i < AGG_N; i += BLOCK) {
+    for (int i = threadIdx.x; i <= (int)g.mask; i += BLOCK) {
         g.keys[i] = EMPTY;
         g.vals[i] = (V)0;
     }
@@ -334,7 +335,7 @@ __device__ __forceinline__ void agg_init(Agg<V> g) {
 
 template <class V>
 __device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *st, uint32_t key, long long d) {
-    uint32_t s = hash32(key) & (AGG_N - 1);
+    uint32_t s = hash32(key) & g.mask;
 #pragma unroll 1
     for (int probe = 0; probe < 8; ++probe) {
         uint32_t k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -346,7 +347,7 @@ __device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *
             atomicAdd(&g.vals[s], (V)d);
             return;
         }
-        s = (s + 1) & (AGG_N - 1);
+        s = (s + 1) & g.mask;
     }
     gt_add(t, st, key, d); // aggregator full around this hash: go straight to HBM
 }
@@ -354,7 +355,7 @@ __device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *
 // slot of `key` in the LDS aggregator (inserting it), or AGG_N when the probe window is full
 template <class V>
 __device__ __forceinline__ uint32_t agg_slot(Agg<V> g, uint32_t key) {
-    uint32_t s = hash32(key) & (AGG_N - 1);
+    uint32_t s = hash32(key) & g.mask;
 #pragma unroll 1
     for (int probe = 0; probe < 8; ++probe) {
         uint32_t k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -363,7 +364,7 @@ __device__ __forceinline__ uint32_t agg_slot(Agg<V> g, uint32_t key) {
             if (k == EMPTY) k = key;
         }
         if (k == key) return s;
-        s = (s + 1) & (AGG_N - 1);
+        s = (s + 1) & g.mask;
     }
     return AGG_N;
 }
@@ -431,8 +432,12 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int i = threadIdx.x + q * BLOCK;
-            k[q] = g.keys[i];
-            v[q] = k[q] == EMPTY ? 0ll : (long long)g.vals[i];
+            k[q] = EMPTY;
+            v[q] = 0;
+            if ((uint32_t)(q * BLOCK) <= g.mask) { // (uniform)
+                k[q] = g.keys[i];
+                v[q] = k[q] == EMPTY ? 0ll : (long long)g.vals[i];
+            }
             mine += v[q] != 0;
         }
         const uint32_t inc = wave_inclusive_sum(mine);
@@ -458,6 +463,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
     if (t.dense) { // direct-indexed counts: every delta is ONE atomic, nothing to look up first
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
+            if ((uint32_t)(q * BLOCK) > g.mask) break; // (uniform)
             const int i = threadIdx.x + q * BLOCK;
             const uint32_t key = g.keys[i];
             const long long val = (long long)g.vals[i];
@@ -468,8 +474,12 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = threadIdx.x + q * BLOCK;
-        k[q] = g.keys[i];
-        v[q] = (long long)g.vals[i];
+        k[q] = EMPTY;
+        v[q] = 0;
+        if ((uint32_t)(q * BLOCK) <= g.mask) { // (uniform)
+            k[q] = g.keys[i];
+            v[q] = (long long)g.vals[i];
+        }
 #ifdef YB_DBG_NOFLUSH
         if (!(k[q] == 12345u && v[q] == 77)) v[q] = 0;
 #endif
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(CountParams P) {
     __shared__ uint32_t s_keys[AGG_N];
     __shared__ unsigned long long s_vals[AGG_N];
     __shared__ __attribute__((aligned(16))) uint16_t s_stage[WPB][8 + CAP + 8];
-    Agg<unsigned long long> agg{s_keys, s_vals};
+    Agg<unsigned long long> agg{s_keys, s_vals, (uint32_t)AGG_N - 1u};
     agg_init(agg);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -649,6 +659,7 @@ struct ApplyParams {
     unsigned long long *sig;       // tile signatures (may be NULL)
     uint32_t sig_stride;
     uint32_t cas_first;            // flush: claim the home slot of a pair that contains the new token without looking first
+    uint32_t agg_mask;             // k_scan_skip: LDS aggregator entries in use - 1 (a power of two - 1, <= AGG_N - 1)
 };
 
 // lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
@@ -1412,7 +1423,7 @@ __global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
     if (blockIdx.x * WPB >= total) return; // nothing for this workgroup (uniform)
     }
 
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b);
@@ -1479,7 +1490,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_skip(ApplySkipParams Q) {
     if (st->done | st->halt) return;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b);
@@ -2437,7 +2448,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     } else {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals}, st, st->a, st->b, st->c, 0u, 0u, lane,
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     const uint32_t newtok = (st->c_is_new && P.cas_first) ? C.c : EMPTY;
     C.mk = yb_memkey(C.a, C.b);
@@ -2553,7 +2564,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     const uint32_t n_blocks = Q.scan_blocks;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals}, st, st_a, st_b, st_c, 0u, 0u, lane,
+    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals, REWRITES ? Q.A.agg_mask : 0u}, st, st_a, st_b, st_c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     const uint32_t a = C.a, b = C.b;
     const uint32_t mk = yb_memkey(a, b);
