@@ -195,7 +195,7 @@ def main() -> None:
     }
     if world > 1:
         out["exchange"] = {"all_gathers": st["exchanges"], "bytes_received_per_merge": st["exchange_bytes"], "record_capacity_per_rank": st["exchange_cap_records"],
-                           "buffer_growths": st["exchange_growths"],
+                           "buffer_growths": st["exchange_growths"], "max_records_of_a_rank_at_a_batch_end": st["exchange_max_records"],
                            "note": "per merge: apply launch (deltas leave as records) -> one all-gather of [header | records] -> one launch that adds "
                                    "every rank's records to the replica and selects the next merge"}
     # ---- what bounds the timed job.  It has two phases:

@@ -189,6 +189,7 @@ struct yabpe_ctx {
     unsigned long long *xsmall = nullptr;  // n_ranks x u64 receive slots for small agreements
     uint8_t *xsend = nullptr, *xrecv = nullptr;  // [DeltaHdr | xcap DeltaRec] of this rank / of every rank
     uint64_t exchange_growths = 0;  // times the exchange buffers had to grow (a merge produced more records than fit)
+    uint64_t exchange_max_records = 0;  // largest record count of one rank seen at a batch end
     uint32_t xcap = 0;      // records per rank per exchange
     uint64_t xstride = 0;   // bytes per rank buffer
     uint64_t exchanges = 0;
@@ -1266,6 +1267,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->fused_launches = 0;
     c->exchanges = 0;
     c->exchange_growths = 0;
+    c->exchange_max_records = 0;
     if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
     c->stats.algo_bytes_total = 0;
     c->have_words = true;
@@ -1666,6 +1668,13 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         TRY(state_pull(c));
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
         if (h->done || h->halt) c->pending = false;          // the last selection of the batch did not select
+        if (c->multi && c->xrecv) {  // (measurement: how full the exchange buffers are -- the last exchange of the batch)
+            for (int r = 0; r < c->n_ranks; ++r) {
+                unsigned long long cnt = 0;
+                HIPCHK(c, hipMemcpy(&cnt, c->xrecv + (uint64_t)r * c->xstride, 8, hipMemcpyDeviceToHost));
+                c->exchange_max_records = std::max<uint64_t>(c->exchange_max_records, cnt);
+            }
+        }
         if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
             unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
             TRY(comm_max(c, sig, &mx));
@@ -1858,6 +1867,7 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.exchange_bytes = c->multi ? c->xstride * (uint64_t)c->n_ranks : 0;
     c->stats.exchange_cap_records = c->xcap;
     c->stats.exchange_growths = c->exchange_growths;
+    c->stats.exchange_max_records = c->exchange_max_records;
     c->stats.scan_skip_launches = c->scan_skip_launches;
     c->stats.scan_skip_tiles_read = 0;
     if (c->blk_read) {
