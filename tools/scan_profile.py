@@ -10,12 +10,14 @@ sys.path.insert(0, str(REPO / "yet-another-bpe_amd"))
 import numpy as np
 from yet_another_bpe import _native, synth
 merges = [int(x) for x in (sys.argv[1:] or ["3000", "20000"])]
+WPB = int(os.environ.get("WPB", "8"))  # waves per workgroup of the sparse launch (forced through the option full_wpb)
 spec = synth.SynthSpec.config3(1024 << 20)
 base = [bytes([b]) for b in range(256)] + [b"<|endoftext|>"]
 NB = 4096
 with _native.Context() as g:
     pb, po, nw, nb = g.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
     with _native.Context() as ctx:
+        ctx.set_option("full_wpb", WPB)
         ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw)
         done = 0
         for m in merges:
@@ -24,9 +26,10 @@ with _native.Context() as g:
             out = np.zeros(NB * 8, dtype=np.uint64)
             _native.lib().yabpe_debug_scan_profile(ctypes.c_void_p(out.ctypes.data), ctypes.c_uint32(NB))
             p = out.reshape(NB, 8).astype(np.int64)
-            n256 = (st["n_tiles"] + 255) // 256; target = 768 if m >= 4000 else 1024  # (full_skip_blocks once merges are sparse)
-            kt = min(4, max(1, -(-n256 // target)))
-            n_scan = min(-(-st["n_tiles"] // (256 * kt)), target)
+            nt = 64 * WPB
+            n256 = (st["n_tiles"] + nt - 1) // nt; target = 256 * 16 // WPB  # (full_skip_blocks: 16 waves per CU)
+            kt = min(2 if WPB >= 16 else 4, max(1, -(-n256 // target)))
+            n_scan = min(-(-st["n_tiles"] // (nt * kt)), target)
             recent = p[:, 7].max() - 30000  # stamps older than 300 us belong to earlier launches
             scan = p[:n_scan]; rank = p[n_scan:]; rank = rank[rank[:, 0] > recent]
             scan = scan[scan[:, 0] > recent]
@@ -48,6 +51,19 @@ with _native.Context() as g:
                     print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us  (n={len(w0)})")
             d = us(scan[:, 7] - scan[:, 0])
             print(f"  {'whole block':28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            fo = np.zeros(NB * 4, dtype=np.uint64)
+            _native.lib().yabpe_debug_flush_profile(ctypes.c_void_p(fo.ctypes.data), ctypes.c_uint32(NB))
+            f = fo.reshape(NB, 4).astype(np.int64)[:n_scan]
+            f = f[p[:n_scan][:, 0] > recent]
+            for nm, d in (("flush: earlier stores acked", us(f[:, 0] - scan[:, 4])), ("flush: table keys arrived", us(f[:, 1] - f[:, 0])),
+                          ("flush: count adds returned", us(f[:, 2] - f[:, 1])), ("flush: rest", us(scan[:, 7] - f[:, 2]))):
+                print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            ne = f[:, 3]
+            print(f"  entries flushed per workgroup: mean {ne.mean():.1f} p99 {np.percentile(ne,99):.0f} max {ne.max()}; tiles read/WG n/a")
+            for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 64), (64, 10**9)):
+                m_ = (ne >= lo) & (ne < hi)
+                if m_.any():
+                    print(f"    WGs with {lo:3d}..{hi if hi < 10**9 else 'inf'} entries: n {m_.sum():5d}  keys {us(f[m_,1]-f[m_,0]).mean():6.2f}  adds {us(f[m_,2]-f[m_,1]).mean():6.2f} (max {us(f[m_,2]-f[m_,1]).max():6.2f})  cand phase {us(scan[m_,2]-scan[m_,1]).mean():6.2f} us")
             ss = (ctypes.c_uint64 * 8)(); _native.lib().yabpe_debug_ss_profile(ss); ss = list(ss)
             if ss[0]:
                 print("  single_site_tile cycles/tile (workgroup 7, cumulative over the run): neighbours %.0f, deltas->LDS %.0f, sig bits %.0f, compaction+stores %.0f  (n=%d)"

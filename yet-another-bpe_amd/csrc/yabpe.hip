@@ -1407,13 +1407,24 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             if (use_sig) {
                 // a grid that is resident all at once (no second round of workgroups behind the first): each thread tests
                 // kt tiles' signatures, a workgroup owns SCAN_CHUNK * kt consecutive tiles at a time
-                const uint32_t n256 = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
                 // sparse merges: the scan also rewrites the few tiles with several sites itself -- no k_slow launch
                 const bool full = c->dense_mode && optv(c, "full_skip", 1);
-                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * 4))
+                // ... and runs with wide workgroups (full_wpb waves, 16 waves per CU either way): a merge late in a job has its
+                // sites in a few word types, so every workgroup with a site adds to the SAME few table counts -- same-address
+                // atomics are served one after the other, and the queue is as long as there are workgroups; a wider
+                // workgroup also evens out how many matched tiles a wave has to rewrite.
+                // (0 = by the merge: 16 waves once a merge has so few sites that the queue on the hot counts is what is
+                // left -- and the whole stream fits one round of such workgroups -- else 8)
+                int64_t wpb_opt = optv(c, "full_wpb", 0);
+                if (wpb_opt <= 0)
+                    wpb_opt = (c->st_host->best_count <= 20ull * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
+                const uint32_t nw = !full ? (uint32_t)WPB : (wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB);
+                const uint32_t nt = nw * 64u;
+                const uint32_t n256 = (c->n_tiles + nt - 1) / nt;
+                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)))
                                              : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
-                const uint32_t kt = std::min<uint32_t>(SCAN_KT_MAX, std::max<uint32_t>(1, (n256 + target - 1) / target));
-                const uint32_t chunk = SCAN_CHUNK * kt;
+                const uint32_t kt = std::min<uint32_t>((uint32_t)scan_kt_max((int)nw), std::max<uint32_t>(1, (n256 + target - 1) / target));
+                const uint32_t chunk = nt * kt;
                 const uint32_t n_chunks = (c->n_tiles + chunk - 1) / chunk;
                 scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n_chunks, target), MAX_LISTS));
                 seg = chunk * ((n_chunks + scan_grid - 1) / scan_grid);
@@ -1425,12 +1436,19 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
                 const bool inl = !c->weighted && optv(c, "inline_single", 1);
                 if (full) {
-                    if (c->weighted)
-                        hipLaunchKernelGGL((k_scan_skip<false, true, true>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
-                    else if (inl)
-                        hipLaunchKernelGGL((k_scan_skip<true, true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
-                    else
-                        hipLaunchKernelGGL((k_scan_skip<false, true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+#define YB_LAUNCH_FULL(NW_)                                                                                                   \
+    do {                                                                                                                      \
+        if (c->weighted)                                                                                                      \
+            hipLaunchKernelGGL((k_scan_skip<false, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);          \
+        else if (inl)                                                                                                         \
+            hipLaunchKernelGGL((k_scan_skip<true, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);          \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_scan_skip<false, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);         \
+    } while (0)
+                    if (nw == 16) YB_LAUNCH_FULL(16);
+                    else if (nw == 8) YB_LAUNCH_FULL(8);
+                    else YB_LAUNCH_FULL(WPB);
+#undef YB_LAUNCH_FULL
                     skip_slow = true;
                 } else if (inl) {
                     hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
@@ -2031,6 +2049,9 @@ int yabpe_debug_launch_profile(unsigned long long *out, int reset) { // 65536 x 
 }
 int yabpe_debug_scan_profile(unsigned long long *out, uint32_t n_blocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_scan_prof), (size_t)std::min<uint32_t>(n_blocks, yb::MAX_LISTS_PROF) * 64) == hipSuccess ? 0 : -1;
+}
+int yabpe_debug_flush_profile(unsigned long long *out, uint32_t n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_flush_prof), (size_t)std::min<uint32_t>(n_blocks, yb::FLUSH_PROF_BLOCKS) * 32) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef YB_PROFILE_SLOW

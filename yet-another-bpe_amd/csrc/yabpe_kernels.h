@@ -40,6 +40,7 @@ constexpr int SIG_TILES = 8;         // k_build_sig: tiles whose signatures one 
 constexpr int MAX_LISTS_PROF = 4096;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time (x kt)
 constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
+constexpr int scan_kt_max(int nw) { return nw >= 16 ? 2 : 4; } // (a workgroup's hit list lives in LDS: 64 * nw * kt entries)
 constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5, HALT_MATRIX_ROWS = 6 };
@@ -316,6 +317,20 @@ __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_
     gt_add_from(t, st, key, d, (t.sink_rec || t.dense) ? 0u : pt_home(t, key), inserted);
 }
 
+#ifdef YB_PROFILE_SCAN
+// (diagnostic build) per workgroup of the last launch: [0] everything issued before the flush acknowledged, [1] table keys
+// arrived, [2] count updates returned (100 MHz wall clock), [3] entries flushed
+constexpr int FLUSH_PROF_BLOCKS = 4096;
+__device__ unsigned long long g_flush_prof[FLUSH_PROF_BLOCKS * 4];
+#define YB_FLUSH_WAIT_STAMP(i)                                                                  \
+    do {                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        __syncthreads();                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < FLUSH_PROF_BLOCKS) g_flush_prof[blockIdx.x * 4 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define YB_FLUSH_WAIT_STAMP(i) do { } while (0)
+#endif
 // ---------------------------------------------------------------- LDS aggregator (per workgroup)
 // V = int for the flat layout (a workgroup's deltas fit 32 bits), unsigned long long for weighted words.
 template <class V>
@@ -326,8 +341,8 @@ struct Agg {
 };
 
 template <class V>
-__device__ __forceinline__ void agg_init(Agg<V> g) {
-    for (int i = threadIdx.x; i <= (int)g.mask; i += BLOCK) {
+__device__ __forceinline__ void agg_init(Agg<V> g, int nt = BLOCK) { // nt: threads of the workgroup
+    for (int i = threadIdx.x; i <= (int)g.mask; i += nt) {
         g.keys[i] = EMPTY;
         g.vals[i] = (V)0;
     }
@@ -414,27 +429,27 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
     if (valid) agg_add(g, t, st, key, (long long)sign);
 }
 
-template <class V>
+template <class V, int NT = BLOCK> // NT: threads of the workgroup
 __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
-    // every thread owns AGG_N / BLOCK entries; the table keys at their home slots are requested together, so that the
+    // every thread owns AGG_N / NT entries; the table keys at their home slots are requested together, so that the
     // usual case (the key sits at its home slot) costs one round trip for all of them.  newtok: the token this merge
     // created (EMPTY: none) -- a pair that contains it cannot be in the table yet, so its home slot is claimed with the
     // compare-and-swap right away instead of being looked at first (one dependent trip fewer for half of a sparse
     // merge's deltas: every site brings two such pairs).
-    constexpr int PER = AGG_N / BLOCK;
+    constexpr int PER = (AGG_N + NT - 1) / NT;
     uint32_t k[PER], home[PER], tk[PER];
     long long v[PER];
     uint32_t ins = 0;
     if (t.sink_rec) { // multi-GPU: the workgroup's deltas leave as records, one reservation in the send buffer per workgroup
-        __shared__ uint32_t s_wtot[WPB];
+        __shared__ uint32_t s_wtot[NT / 64];
         __shared__ unsigned long long s_sbase;
         uint32_t mine = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const int i = threadIdx.x + q * BLOCK;
+            const int i = threadIdx.x + q * NT;
             k[q] = EMPTY;
             v[q] = 0;
-            if ((uint32_t)(q * BLOCK) <= g.mask) { // (uniform)
+            if ((uint32_t)i <= g.mask) {
                 k[q] = g.keys[i];
                 v[q] = k[q] == EMPTY ? 0ll : (long long)g.vals[i];
             }
@@ -446,7 +461,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t tot = 0;
-            for (int w = 0; w < WPB; ++w) tot += s_wtot[w];
+            for (int w = 0; w < NT / 64; ++w) tot += s_wtot[w];
             s_sbase = tot ? atomicAdd(&t.sink_hdr->count, (unsigned long long)tot) : 0ull;
         }
         __syncthreads();
@@ -463,20 +478,21 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
     if (t.dense) { // direct-indexed counts: every delta is ONE atomic, nothing to look up first
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            if ((uint32_t)(q * BLOCK) > g.mask) break; // (uniform)
-            const int i = threadIdx.x + q * BLOCK;
+            const int i = threadIdx.x + q * NT;
+            if ((uint32_t)i > g.mask) continue;
             const uint32_t key = g.keys[i];
             const long long val = (long long)g.vals[i];
             if (key != EMPTY && val != 0) gt_bump_dense(t, key, val);
         }
         return;
     }
+    YB_FLUSH_WAIT_STAMP(0);
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const int i = threadIdx.x + q * BLOCK;
+        const int i = threadIdx.x + q * NT;
         k[q] = EMPTY;
         v[q] = 0;
-        if ((uint32_t)(q * BLOCK) <= g.mask) { // (uniform)
+        if ((uint32_t)i <= g.mask) {
             k[q] = g.keys[i];
             v[q] = (long long)g.vals[i];
         }
@@ -499,6 +515,19 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             }
         }
     }
+    YB_FLUSH_WAIT_STAMP(1);
+#ifdef YB_PROFILE_SCAN
+    {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) nz += v[q] != 0;
+        if (blockIdx.x < FLUSH_PROF_BLOCKS) {
+            if (threadIdx.x == 0) g_flush_prof[blockIdx.x * 4 + 3] = 0;
+            __syncthreads();
+            if (nz) atomicAdd(&g_flush_prof[blockIdx.x * 4 + 3], (unsigned long long)nz);
+        }
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         if (v[q] == 0) continue;
@@ -510,6 +539,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             gt_add_from(t, st, k[q], v[q], pt_next(t, home[q]), &ins); // (home holds another key)
         }
     }
+    YB_FLUSH_WAIT_STAMP(2);
     // new keys of this wave (ins <= PER per thread): three ballots give the total
     uint32_t total = 0;
 #pragma unroll
@@ -1119,7 +1149,7 @@ __device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
 }
 
 // per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
-template <class AggV>
+template <class AggV, int NT = BLOCK>
 __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> agg, DevState *st, unsigned long long *s_cnt,
                                                unsigned long long wave_sites, unsigned long long wave_freed, int lane, uint32_t newtok = EMPTY) {
     if (lane == 0) {
@@ -1131,7 +1161,7 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
         st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]); // (it may run in this very launch)
         st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
     }
-    agg_flush(agg, P.out, st, newtok);
+    agg_flush<AggV, NT>(agg, P.out, st, newtok);
 }
 
 // ---------------------------------------------------------------- split form, pass 1: pure streaming scan
@@ -2383,6 +2413,7 @@ __device__ __forceinline__ void fused_select_tail(const FuseParams &F) {
     if (!F.ticket) return;
     YB_SEL_STAMP(0);
     if (!last_workgroup(F.ticket)) return;
+    if (threadIdx.x >= BLOCK) return; // (a wider workgroup: the selection is written for BLOCK threads; ended waves are not waited for)
     YB_SEL_STAMP(8);
     select_body<true>(F.sel, best_ex_none());
 }
@@ -2532,17 +2563,20 @@ struct ScanSkipParams {
 // balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.  In this form
 // matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
 // already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
-template <bool INLINE, bool FULL, bool WEIGHTED>
+template <bool INLINE, bool FULL, bool WEIGHTED, int NW>
 __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // false: stop flag set, nothing done (grid-uniform)
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     constexpr bool REWRITES = INLINE || FULL;
+    constexpr int NT = NW * 64;                   // threads of the workgroup (NW waves)
+    constexpr int KTM = scan_kt_max(NW);
+    static_assert(FULL || NW == WPB, "only the sparse form runs with wider workgroups");
     static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
     __shared__ uint32_t s_n, s_hits, s_nrew;
-    __shared__ uint2 s_list[SCAN_CHUNK * SCAN_KT_MAX];
-    __shared__ uint2 s_rew[REWRITES ? SCAN_CHUNK * SCAN_KT_MAX : 1];
+    __shared__ uint2 s_list[NT * KTM];
+    __shared__ uint2 s_rew[(REWRITES && !FULL) ? NT * KTM : 1];
     __shared__ uint32_t s_keys[REWRITES ? AGG_N : 1];
     __shared__ AggV s_vals[REWRITES ? AGG_N : 1];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? WPB : 1];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? NW : 1];
     __shared__ unsigned long long s_cnt[2];
     const ScanParams &P = Q.S;
     DevState *st = P.st;
@@ -2556,6 +2590,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     YB_LAUNCH_START(prof_it);
 #endif
     if (blockIdx.x >= Q.scan_blocks) {
+        if (NW > WPB && threadIdx.x >= BLOCK) return false; // (lexrank maintenance is written for BLOCK threads: the other waves end here)
         rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
         YB_SCAN_STAMP(7);
         YB_LAUNCH_END(prof_it);
@@ -2573,7 +2608,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
     const bool single_ok = INLINE && a != b;
     const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
-    if (REWRITES) agg_init(C.agg);
+    if (REWRITES) agg_init(C.agg, NT);
     WaveLds &W = s_w[FULL ? wib : 0];
     if (FULL) wave_lds_init(W, lane);
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -2587,15 +2622,15 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t kt = Q.kt;
-    const uint32_t chunk = SCAN_CHUNK * kt;
+    const uint32_t chunk = NT * kt;
     const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
     for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
         // all of this thread's signature words are requested before the first one is looked at
-        uint32_t len[SCAN_KT_MAX];
-        bool maybe[SCAN_KT_MAX];
+        uint32_t len[KTM];
+        bool maybe[KTM];
 #pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
-            const uint32_t t = ch * chunk + j * SCAN_CHUNK + threadIdx.x;
+        for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
+            const uint32_t t = ch * chunk + j * NT + threadIdx.x;
             len[j] = 0;
             maybe[j] = false;
             if (j < kt && t < P.n_tiles) {
@@ -2605,14 +2640,14 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         }
         YB_SCAN_STAMP(1);
 #pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)SCAN_KT_MAX; ++j) {
+        for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
             if (j >= kt) break; // uniform
             const bool mb = maybe[j] && len[j] != 0;
             const unsigned long long m = __ballot(mb);
             uint32_t base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * SCAN_CHUNK + threadIdx.x, len[j]);
+            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * NT + threadIdx.x, len[j]);
         }
         __syncthreads();
         const uint32_t n = s_n;
@@ -2622,8 +2657,8 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         constexpr bool DEEP = !FULL;
         uint32_t j = wib;
         uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
-        uint2 it1 = j + WPB < n ? s_list[j + WPB] : make_uint2(0u, 0u);
-        uint2 it2 = DEEP && j + 2 * WPB < n ? s_list[j + 2 * WPB] : make_uint2(0u, 0u);
+        uint2 it1 = j + NW < n ? s_list[j + NW] : make_uint2(0u, 0u);
+        uint2 it2 = DEEP && j + 2 * NW < n ? s_list[j + 2 * NW] : make_uint2(0u, 0u);
         TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
         TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
         TileRegs q2 = q1;
@@ -2633,16 +2668,16 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
             const TileRegs r = q0;
             it0 = it1;
             q0 = q1;
-            j += WPB;
+            j += NW;
             if constexpr (DEEP) {
                 it1 = it2;
                 q1 = q2;
-                if (j + 2 * WPB < n) {
-                    it2 = s_list[j + 2 * WPB];
+                if (j + 2 * NW < n) {
+                    it2 = s_list[j + 2 * NW];
                     q2 = load_tile(P.tiles, it2.x, it2.y, lane);
                 }
-            } else if (j + WPB < n) {
-                it1 = s_list[j + WPB];
+            } else if (j + NW < n) {
+                it1 = s_list[j + NW];
                 q1 = load_tile(P.tiles, it1.x, it1.y, lane);
             }
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
@@ -2682,7 +2717,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
             const uint32_t nr = s_nrew;
             uint32_t k = wib;
             uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
-            uint2 w1 = k + WPB < nr ? s_rew[k + WPB] : make_uint2(0u, 0u);
+            uint2 w1 = k + NW < nr ? s_rew[k + NW] : make_uint2(0u, 0u);
             TileRegs t0 = load_tile(P.tiles, w0.x, w0.y, lane); // L2 hits: the tile was read a moment ago
             TileRegs t1 = load_tile(P.tiles, w1.x, w1.y, lane);
             while (k < nr) {
@@ -2690,9 +2725,9 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
                 const TileRegs r = t0;
                 w0 = w1;
                 t0 = t1;
-                k += WPB;
-                if (k + WPB < nr) {
-                    w1 = s_rew[k + WPB];
+                k += NW;
+                if (k + NW < nr) {
+                    w1 = s_rew[k + NW];
                     t1 = load_tile(P.tiles, w1.x, w1.y, lane);
                 }
                 const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
@@ -2703,7 +2738,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
 #ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)WPB) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
+                if (k == (uint32_t)NW) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
 #endif
                 bool handled = false;
                 if constexpr (INLINE) {
@@ -2719,7 +2754,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
                     my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
                 }
 #ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)WPB) YB_SCAN_STAMP(6);
+                if (k == (uint32_t)NW) YB_SCAN_STAMP(6);
 #endif
             }
             __syncthreads();
@@ -2747,14 +2782,14 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
     }
     YB_SCAN_STAMP(4);
-    if (REWRITES) apply_epilogue(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane, (st_new && Q.A.cas_first) ? st_c : EMPTY);
+    if (REWRITES) apply_epilogue<AggV, NT>(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane, (st_new && Q.A.cas_first) ? st_c : EMPTY);
     YB_SCAN_STAMP(7);
     YB_LAUNCH_END(prof_it);
     return true;
 }
-template <bool INLINE, bool FULL, bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK, FULL ? 4 : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 4 workgroups per CU)
-    if (!scan_skip_block<INLINE, FULL, WEIGHTED>(Q)) return;
+template <bool INLINE, bool FULL, bool WEIGHTED, int NW = WPB>
+__global__ __launch_bounds__(NW * 64, FULL ? 16 / NW : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 16 waves per CU)
+    if (!scan_skip_block<INLINE, FULL, WEIGHTED, NW>(Q)) return;
     if constexpr (FULL) fused_select_tail(Q.F);
 }
 
