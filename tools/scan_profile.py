@@ -68,6 +68,8 @@ with _native.Context() as g:
             if ss[0]:
                 print("  single_site_tile cycles/tile (workgroup 7, cumulative over the run): neighbours %.0f, deltas->LDS %.0f, sig bits %.0f, compaction+stores %.0f  (n=%d)"
                       % (ss[1] / ss[0], ss[2] / ss[0], ss[3] / ss[0], ss[4] / ss[0], ss[0]))
+                if ss[6]:
+                    print("  ... and then until the tile's stores and signature atomics are acknowledged: %.0f cycles (n=%d)" % (ss[5] / ss[6], ss[6]))
             sp = (ctypes.c_uint64 * 16)(); _native.lib().yabpe_debug_sel_profile(sp); sp = [int(v) for v in sp]
             rel = lambda i: (sp[i] - sp[0]) / 100.0
             print("  k_argmax_cand wg0: state loaded %.2f | list evaluated %.2f | bitmap evaluated %.2f us" % (rel(10), rel(11), rel(12)))

@@ -202,6 +202,13 @@ __device__ __forceinline__ SigProbe sig_probe(const unsigned long long *sig, uin
     return SigProbe{sig + (size_t)H.row * stride, H.mask};
 }
 
+// End of a RARE branch that issued returning global atomics (an update that bypasses the LDS aggregator): wait for them
+// here.  Their destination registers are otherwise still "pending" where the branch rejoins the common path, and the
+// compiler then guards the next reuse of those registers with s_waitcnt vmcnt(0) ON THE COMMON PATH -- which waits for
+// every store and prefetch the wave has in flight (measured: ~1 us per rewritten tile).  (The builtin, not inline asm:
+// the wait-count pass has to see it.)  gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15.
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // Within one wave LDS operations complete in order; this keeps the compiler from moving a lane's LDS reads
 // above other lanes' LDS writes.
 __device__ __forceinline__ void wave_sync() {
@@ -365,6 +372,7 @@ __device__ __forceinline__ void agg_add(Agg<V> g, const PairTable &t, DevState *
         s = (s + 1) & g.mask;
     }
     gt_add(t, st, key, d); // aggregator full around this hash: go straight to HBM
+    vm_drain();            // (rare path; see vm_drain)
 }
 
 // slot of `key` in the LDS aggregator (inserting it), or AGG_N when the probe window is full
@@ -417,10 +425,12 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
                 memo.slot[role] = slot;
             }
             if (lane == leader) {
-                if (slot < (uint32_t)AGG_N)
+                if (slot < (uint32_t)AGG_N) {
                     atomicAdd(&g.vals[slot], sum);
-                else
+                } else {
                     gt_add(t, st, k, (long long)sum); // aggregator full around this hash: straight to HBM
+                    vm_drain();
+                }
             }
         }
         pend &= ~same;
@@ -886,25 +896,9 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     const bool dead = !left && R == YB_SEP; // the word was exactly (a b): it leaves the stream (yb_site_word_dies)
 
     YB_SS_STAMP(1);
-    // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1, one per lane: the four
-    // aggregator probes run side by side instead of one after the other
-    {
-        const uint32_t kl = lane & 1 ? yb_pairkey(L, c) : yb_pairkey(L, a);
-        const uint32_t kr = lane & 1 ? yb_pairkey(c, R) : yb_pairkey(b, R);
-        const bool on = lane < 4 && (lane < 2 ? left : right);
-        if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
-    }
-    YB_SS_STAMP(2);
-    // the two pairs this site creates are now present in the tile: one signature word each, set by lanes 0 and 1
-#ifdef YB_DBG_NOSIGSET
-    if (false) {
-#else
-    if (P.sig && !dead && lane < 2) {
-#endif
-        if (lane ? right : left) sig_set_pair(P.sig, P.sig_stride, tile, lane ? yb_pairkey(c, R) : yb_pairkey(L, c));
-    }
-    YB_SS_STAMP(3);
-
+    // (order: the stores go out FIRST -- the signature bits and the LDS deltas below run while they are acknowledged; the
+    // candidate loop cannot take the next tile's prefetched registers before this wave's outstanding stores are back,
+    // the in-order vmcnt leaves the compiler no other choice)
     // ---- compaction in registers
     const int D0 = dead ? p : p + 1; // first slot that leaves
     const int s = dead ? 3 : 1;      // how many leave (contiguous)
@@ -957,6 +951,24 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     }
     if (lane == 0) P.tile_len[tile] = new_len;
     YB_SS_STAMP(4);
+    // the two pairs this site creates are now present in the tile: one signature word each, set by lanes 0 and 1
+#ifdef YB_DBG_NOSIGSET
+    if (false) {
+#else
+    if (P.sig && !dead && lane < 2) {
+#endif
+        if (lane ? right : left) sig_set_pair(P.sig, P.sig_stride, tile, lane ? yb_pairkey(c, R) : yb_pairkey(L, c));
+    }
+    YB_SS_STAMP(3);
+    // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1, one per lane: the four
+    // aggregator probes run side by side instead of one after the other
+    {
+        const uint32_t kl = lane & 1 ? yb_pairkey(L, c) : yb_pairkey(L, a);
+        const uint32_t kr = lane & 1 ? yb_pairkey(c, R) : yb_pairkey(b, R);
+        const bool on = lane < 4 && (lane < 2 ? left : right);
+        if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
+    }
+    YB_SS_STAMP(2);
     wave_sites += 1;
     wave_freed += (unsigned long long)s;
 }
@@ -2697,6 +2709,17 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
                     if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
                         single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
                         handled = true;
+#ifdef YB_PROFILE_SCAN // how long until everything this tile stored is acknowledged (what a conservative vmcnt(0) costs)
+                        {
+                            const unsigned long long t0 = __builtin_readcyclecounter();
+                            vm_drain();
+                            const unsigned long long t1 = __builtin_readcyclecounter();
+                            if (lane == 0 && blockIdx.x == 7) {
+                                atomicAdd(&g_ss_prof[5], t1 - t0);
+                                atomicAdd(&g_ss_prof[6], 1ull);
+                            }
+                        }
+#endif
                     }
                 }
                 if (handled) {
