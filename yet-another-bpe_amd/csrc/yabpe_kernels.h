@@ -2595,6 +2595,19 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     YB_SCAN_STAMP(0);
     // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
     const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c, st_new = st->c_is_new;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (the LDS tables do not depend on the merge: they are cleared while the loads above are on their way)
+    if (blockIdx.x < Q.scan_blocks) {
+        if (REWRITES) agg_init(Agg<AggV>{s_keys, s_vals, Q.A.agg_mask}, NT);
+        if (FULL) wave_lds_init(s_w[wib], lane);
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_hits = 0;
+            s_nrew = 0;
+        }
+    }
     if (st_stop) return false; // (the same answer in every workgroup: nobody takes a ticket)
     if (FULL) YB_SCAN_STAMP(5); // (profile build: the merge has arrived)
 #ifdef YB_PROFILE_LAUNCH
@@ -2609,8 +2622,6 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
         return true;
     }
     const uint32_t n_blocks = Q.scan_blocks;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals, REWRITES ? Q.A.agg_mask : 0u}, st, st_a, st_b, st_c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
     const uint32_t a = C.a, b = C.b;
@@ -2620,15 +2631,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
     const bool single_ok = INLINE && a != b;
     const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
-    if (REWRITES) agg_init(C.agg, NT);
     WaveLds &W = s_w[FULL ? wib : 0];
-    if (FULL) wave_lds_init(W, lane);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        s_n = 0;
-        s_hits = 0;
-        s_nrew = 0;
-    }
     __syncthreads();
     if (FULL) YB_SCAN_STAMP(6); // (profile build: LDS tables initialised)
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
