@@ -92,6 +92,7 @@ struct EventPair {
 struct yabpe_ctx {
     int device = 0;
     int n_cu = 256;
+    int apply_occ = 4;  // workgroups of the streaming-phase kernels that one CU holds at a time (asked of the runtime at creation)
     hipStream_t stream = nullptr;
     std::string err;
     std::map<std::string, int64_t> opt;
@@ -549,7 +550,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
 
 uint32_t count_grid(yabpe_ctx *c) {
     uint32_t want = (c->n_tiles + WPB - 1) / WPB;
-    uint32_t cap = (uint32_t)optv(c, "apply_blocks", (int64_t)c->n_cu * 5);
+    uint32_t cap = (uint32_t)optv(c, "apply_blocks", (int64_t)c->n_cu * c->apply_occ);
     return std::max(1u, std::min(std::min(want, cap), MAX_APPLY_BLOCKS));
 }
 
@@ -951,6 +952,18 @@ int yabpe_create(yabpe_ctx **out, int device_id) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // The streaming-phase grid must be resident all at once: its workgroups stride over the tiles and all finish together, so
+        // a workgroup that has to wait for a free slot runs alone afterwards (5 per CU asked, 4 resident: +25 % on every launch).
+        int occ = 0, lo = 1 << 30;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_apply<false, false>, BLOCK, 0) == hipSuccess && occ > 0) lo = std::min(lo, occ);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_apply<false, true>, BLOCK, 0) == hipSuccess && occ > 0) lo = std::min(lo, occ);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_apply<true, false>, BLOCK, 0) == hipSuccess && occ > 0) lo = std::min(lo, occ);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_count<false>, BLOCK, 0) == hipSuccess && occ > 0) lo = std::min(lo, occ);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_count<true>, BLOCK, 0) == hipSuccess && occ > 0) lo = std::min(lo, occ);
+        (void)hipGetLastError();
+        c->apply_occ = lo == (1 << 30) ? 4 : lo;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&c->st, sizeof(DevState)) != hipSuccess ||
         hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
@@ -1381,6 +1394,8 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
                 hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
+            else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V)  // (every token id this launch can meet indexes the direct store)
+                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
             else
                 hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));

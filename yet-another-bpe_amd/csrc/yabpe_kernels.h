@@ -439,14 +439,19 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
     if (valid) agg_add(g, t, st, key, (long long)sign);
 }
 
-template <class V, int NT = BLOCK> // NT: threads of the workgroup
-__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+// get(i) -> FlushEnt: entry i of the workgroup's delta store (key EMPTY or val 0: nothing); N_ENT entries, NT threads.
+struct FlushEnt {
+    uint32_t key;
+    long long val;
+};
+template <int NT, int N_ENT, class GetF>
+__device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
     // every thread owns AGG_N / NT entries; the table keys at their home slots are requested together, so that the
     // usual case (the key sits at its home slot) costs one round trip for all of them.  newtok: the token this merge
     // created (EMPTY: none) -- a pair that contains it cannot be in the table yet, so its home slot is claimed with the
     // compare-and-swap right away instead of being looked at first (one dependent trip fewer for half of a sparse
     // merge's deltas: every site brings two such pairs).
-    constexpr int PER = (AGG_N + NT - 1) / NT;
+    constexpr int PER = (N_ENT + NT - 1) / NT;
     uint32_t k[PER], home[PER], tk[PER];
     long long v[PER];
     uint32_t ins = 0;
@@ -459,10 +464,12 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
             const int i = threadIdx.x + q * NT;
             k[q] = EMPTY;
             v[q] = 0;
-            if ((uint32_t)i <= g.mask) {
-                k[q] = g.keys[i];
-                v[q] = k[q] == EMPTY ? 0ll : (long long)g.vals[i];
+            if (i < N_ENT) {
+                const FlushEnt e = get(i);
+                k[q] = e.key;
+                v[q] = e.val;
             }
+            if (k[q] == EMPTY) v[q] = 0;
             mine += v[q] != 0;
         }
         const uint32_t inc = wave_inclusive_sum(mine);
@@ -489,10 +496,9 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int i = threadIdx.x + q * NT;
-            if ((uint32_t)i > g.mask) continue;
-            const uint32_t key = g.keys[i];
-            const long long val = (long long)g.vals[i];
-            if (key != EMPTY && val != 0) gt_bump_dense(t, key, val);
+            if (i >= N_ENT) continue;
+            const FlushEnt e = get(i);
+            if (e.key != EMPTY && e.val != 0) gt_bump_dense(t, e.key, e.val);
         }
         return;
     }
@@ -502,9 +508,10 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
         const int i = threadIdx.x + q * NT;
         k[q] = EMPTY;
         v[q] = 0;
-        if ((uint32_t)i <= g.mask) {
-            k[q] = g.keys[i];
-            v[q] = (long long)g.vals[i];
+        if (i < N_ENT) {
+            const FlushEnt e = get(i);
+            k[q] = e.key;
+            v[q] = e.val;
         }
 #ifdef YB_DBG_NOFLUSH
         if (!(k[q] == 12345u && v[q] == 77)) v[q] = 0;
@@ -550,11 +557,47 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
         }
     }
     YB_FLUSH_WAIT_STAMP(2);
-    // new keys of this wave (ins <= PER per thread): three ballots give the total
+    // new keys of this wave (ins <= 2 * PER per thread): a few ballots give the total
     uint32_t total = 0;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) total += (uint32_t)__popcll(__ballot((ins >> b) & 1u)) << b;
+    for (int b = 0; b < 5; ++b) total += (uint32_t)__popcll(__ballot((ins >> b) & 1u)) << b;
     if (total && (threadIdx.x & 63) == 0) atomicAdd(t.entries, (unsigned long long)total);
+}
+
+template <class V, int NT = BLOCK> // NT: threads of the workgroup
+__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+    flush_entries<NT, AGG_N>(
+        [&](int i) -> FlushEnt {
+            if ((uint32_t)i > g.mask) return FlushEnt{EMPTY, 0ll};
+            return FlushEnt{g.keys[i], (long long)g.vals[i]};
+        },
+        t, st, newtok);
+}
+
+// Direct-indexed form of the per-workgroup delta store, for the first merges of a job (few tokens, many sites per tile):
+// every delta of a merge (a,b) -> c has one FIXED half -- (x,a) -1, (x,c) +1, (b,y) -1, (c,y) +1 (tile_logic.h: x is the
+// left neighbour, or b / c when the neighbour is itself a site; y the right neighbour) -- so the other half indexes one of
+// four small LDS arrays directly: a delta is ONE fire-and-forget LDS add, no hashing, no probing, no peeling of hot keys.
+constexpr int HIST_V = 512; // tokens that may exist while this form is used (the host checks)
+struct Hist {
+    int *h; // [4][HIST_V]: role 0 (x,a), 1 (x,c), 2 (b,y), 3 (c,y)
+};
+__device__ __forceinline__ void hist_init(Hist H) {
+    for (int i = threadIdx.x; i < 4 * HIST_V; i += BLOCK) H.h[i] = 0;
+}
+__device__ __forceinline__ void hist_flush(Hist H, uint32_t a, uint32_t b, uint32_t c, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+    // one role at a time (two entries per thread): eight entries per thread in one go do not stay in registers
+#pragma unroll 1
+    for (uint32_t role = 0; role < 4; ++role) {
+        const uint32_t fixed = role == 0 ? a : role == 2 ? b : c;
+        flush_entries<BLOCK, HIST_V>(
+            [&](int i) -> FlushEnt {
+                const int v = H.h[role * HIST_V + i];
+                const uint32_t key = role < 2 ? yb_pairkey((uint32_t)i, fixed) : yb_pairkey(fixed, (uint32_t)i);
+                return FlushEnt{v ? key : EMPTY, (long long)v};
+            },
+            t, st, newtok);
+    }
 }
 
 // ---------------------------------------------------------------- tile access helpers
@@ -844,6 +887,7 @@ struct SlowCtx {
     uint32_t a, b, c, mk, self;
     int lane;
     KeyMemo memo; // wave-uniform
+    int *hist;    // != NULL: the direct-indexed delta store (Hist) is in use instead of agg
 };
 
 // slot q of the tile (wave-uniform q), read out of the registers that hold the tile: lane (q>>3)&63 owns it
@@ -877,7 +921,7 @@ __device__ unsigned long long g_ss_prof[8];
 // the compaction is a funnel shift in registers -- the slots that leave the tile are one contiguous run (the b, or the
 // whole word (c, b, SEP) when the word was exactly (a b)), so every later slot moves left by the same s in {1, 3}.
 // No LDS staging, no bitmaps, no scatter.
-template <class AggV>
+template <class AggV, bool HIST = false>
 __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile, uint32_t len, const TileRegs &r,
                                                  int lane_s, uint32_t mm_s, unsigned long long &wave_sites,
                                                  unsigned long long &wave_freed) {
@@ -966,7 +1010,11 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         const uint32_t kl = lane & 1 ? yb_pairkey(L, c) : yb_pairkey(L, a);
         const uint32_t kr = lane & 1 ? yb_pairkey(c, R) : yb_pairkey(b, R);
         const bool on = lane < 4 && (lane < 2 ? left : right);
-        if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
+        if constexpr (HIST) { // lane = role: (L,a) -1, (L,c) +1, (b,R) -1, (c,R) +1
+            if (on) atomicAdd(&C.hist[lane * HIST_V + (int)(lane < 2 ? L : R)], (lane & 1) ? 1 : -1);
+        } else {
+            if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
+        }
     }
     YB_SS_STAMP(2);
     wave_sites += 1;
@@ -975,7 +1023,7 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
 
 // Rewrites one tile that contains at least one candidate site: pair-count deltas, drop bitmap, compaction,
 // write-back.  Work is proportional to the number of sites.  Returns false when nothing changed.
-template <bool WEIGHTED, class AggV>
+template <bool WEIGHTED, class AggV, bool HIST = false>
 __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
                                           uint32_t na, uint32_t nb, unsigned long long &wave_sites,
                                           unsigned long long &wave_freed) {
@@ -1002,7 +1050,7 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s);
                 if (__popc(mm_s) == 1) {
-                    single_site_tile(C, tile, len, r, lane_s, mm_s, wave_sites, wave_freed);
+                    single_site_tile<AggV, HIST>(C, tile, len, r, lane_s, mm_s, wave_sites, wave_freed);
                     return true;
                 }
             }
@@ -1085,6 +1133,12 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
                     agg_add(C.agg, P.out, st, d.rn, +w);
                 }
             }
+        } else if constexpr (HIST) { // (every delta has one fixed half: the other one is the index -- see Hist)
+            static_assert(!WEIGHTED, "the direct-indexed store holds 32-bit deltas");
+            if (d.left && d.lo != self) atomicAdd(&C.hist[0 * HIST_V + (int)(d.lo >> 16)], -1);
+            if (d.left) atomicAdd(&C.hist[1 * HIST_V + (int)(d.ln >> 16)], 1);
+            if (d.right && d.ro != self) atomicAdd(&C.hist[2 * HIST_V + (int)(d.ro & 0xffffu)], -1);
+            if (d.right) atomicAdd(&C.hist[3 * HIST_V + (int)(d.rn & 0xffffu)], 1);
         } else {
             agg_add_wave(C.agg, P.out, st, d.left && d.lo != self, d.lo, -1, lane, C.memo, 0);
             agg_add_wave(C.agg, P.out, st, d.left, d.ln, +1, lane, C.memo, 1);
@@ -1163,7 +1217,8 @@ __device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
 // per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
 template <class AggV, int NT = BLOCK>
 __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> agg, DevState *st, unsigned long long *s_cnt,
-                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane, uint32_t newtok = EMPTY) {
+                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane, uint32_t newtok = EMPTY,
+                                               int *hist = nullptr, uint32_t ha = 0, uint32_t hb = 0, uint32_t hc = 0) {
     if (lane == 0) {
         if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
         if (wave_freed) atomicAdd(&s_cnt[1], wave_freed);
@@ -1173,7 +1228,10 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
         st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]); // (it may run in this very launch)
         st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
     }
-    agg_flush<AggV, NT>(agg, P.out, st, newtok);
+    if (hist) // (the direct-indexed store of merge (ha, hb) -> hc)
+        hist_flush(Hist{hist}, ha, hb, hc, P.out, st, newtok);
+    else
+        agg_flush<AggV, NT>(agg, P.out, st, newtok);
 }
 
 // ---------------------------------------------------------------- split form, pass 1: pure streaming scan
@@ -2475,11 +2533,14 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
 // ================================================================ the per-merge launches (they end with the fused selection)
 // ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
 // (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
-template <bool WEIGHTED>
+// HIST (flat layout, at most HIST_V tokens): the deltas go to the direct-indexed LDS store (Hist) instead of the hashed one.
+template <bool WEIGHTED, bool HIST = false>
 __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    __shared__ uint32_t s_keys[AGG_N];
-    __shared__ AggV s_vals[AGG_N];
+    static_assert(!(HIST && WEIGHTED), "the direct-indexed store holds 32-bit deltas");
+    __shared__ uint32_t s_keys[HIST ? 1 : AGG_N];
+    __shared__ AggV s_vals[HIST ? 1 : AGG_N];
+    __shared__ int s_hist[HIST ? 4 * HIST_V : 1];
     __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
     __shared__ unsigned long long s_cnt[2];
 
@@ -2491,13 +2552,13 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     } else {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_hist : nullptr};
     const uint32_t newtok = (st->c_is_new && P.cas_first) ? C.c : EMPTY;
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
     const uint32_t mk = C.mk;
-    agg_init(C.agg);
+    if constexpr (HIST) hist_init(Hist{s_hist}); else agg_init(C.agg);
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     WaveLds &W = s_w[wib];
     wave_lds_init(W, lane);
@@ -2525,13 +2586,13 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+            slow_tile<WEIGHTED, AggV, HIST>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
         }
     }
 #ifdef YB_PROFILE_SLOW
     if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
 #endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, newtok);
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, newtok, HIST ? s_hist : nullptr, C.a, C.b, C.c);
     }
     fused_select_tail(F);
 }
