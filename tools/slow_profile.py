@@ -25,3 +25,4 @@ names = ["", "stage+masks", "site loop (deltas, sig, agg)", "prefix+scatter", "w
 for i in range(1, 5):
     print(f"{names[i]:32s} {d[i]/max(d[0],1):10.0f} cycles/tile")
 print("total cycles/tile", sum(d[1:5]) / max(d[0], 1))
+print(f"between two rewrites (wait for the next tile + match) {d[5]/max(d[0],1):10.0f} cycles/tile")

@@ -2566,6 +2566,9 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 
     unsigned long long wave_sites = 0; // wave-uniform
     unsigned long long wave_freed = 0; // slots removed from this wave's tiles
+#ifdef YB_PROFILE_SLOW
+    unsigned long long t_end = 0;
+#endif
     const uint32_t stride = apply_blocks * WPB;
     const uint32_t n_tiles = P.n_tiles;
     // A wave walks tiles w, w+stride, w+2*stride, ...; 64 tile lengths are fetched with one vector load and the
@@ -2586,7 +2589,13 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
             if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+#ifdef YB_PROFILE_SLOW // [5]: from the end of one rewrite to the start of the next (the wait for the tile, the match)
+            if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
+#endif
             slow_tile<WEIGHTED, AggV, HIST>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+#ifdef YB_PROFILE_SLOW
+            t_end = __builtin_readcyclecounter();
+#endif
         }
     }
 #ifdef YB_PROFILE_SLOW
