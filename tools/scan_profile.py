@@ -58,6 +58,10 @@ with _native.Context() as g:
             for nm, d in (("flush: earlier stores acked", us(f[:, 0] - scan[:, 4])), ("flush: table keys arrived", us(f[:, 1] - f[:, 0])),
                           ("flush: count adds returned", us(f[:, 2] - f[:, 1])), ("flush: rest", us(scan[:, 7] - f[:, 2]))):
                 print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")
+            late = np.argsort(scan[:, 7])[-max(8, len(scan) // 20):]  # the workgroups that finish last: what the launch waits for
+            print(f"  the last {len(late)} workgroups to finish: start->sig {us(scan[late,1]-scan[late,0]).mean():.2f}  candidates {us(scan[late,2]-scan[late,1]).mean():.2f}"
+                  f"  flush: stores acked {us(f[late,0]-scan[late,4]).mean():.2f} keys {us(f[late,1]-f[late,0]).mean():.2f} adds {us(f[late,2]-f[late,1]).mean():.2f} rest {us(scan[late,7]-f[late,2]).mean():.2f}"
+                  f"  | end at {us(scan[late,7]-t0).mean():.2f} (all: {us(scan[:,7]-t0).mean():.2f}) entries {f[late,3].mean():.1f}")
             ne = f[:, 3]
             print(f"  entries flushed per workgroup: mean {ne.mean():.1f} p99 {np.percentile(ne,99):.0f} max {ne.max()}; tiles read/WG n/a")
             for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 64), (64, 10**9)):

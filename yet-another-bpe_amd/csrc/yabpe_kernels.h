@@ -218,6 +218,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+// how many bits of the wave mask m lie below this lane (v_mbcnt: no per-lane 64-bit mask to keep in registers)
+__device__ __forceinline__ uint32_t bits_below_lane(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar): Hillis-Steele inside each row of 16
 // lanes (row_shr 1,2,4,8; lanes without a source add 0), then the row totals travel with row_bcast:15 / row_bcast:31.
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(CountParams P) {
             long long w = 1;
             if (WEIGHTED) {
                 unsigned long long sm = __ballot(x == YB_SEP);
-                uint32_t widx = sep_carry + __popcll(sm & lanemask_lt(lane));
+                uint32_t widx = sep_carry + bits_below_lane(sm);
                 sep_carry += __popcll(sm);
                 if (x < YB_PAD && y < YB_PAD) w = (long long)P.wfreq[widx];
             }
@@ -962,14 +966,17 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         const uint32_t n1 = next_lane(v.y, seg ? PADPAD : fy);
         const uint32_t n2 = next_lane(v.z, seg ? PADPAD : fz);
         uint32_t U0 = v.x, U1 = v.y, U2 = v.z, U3 = v.w;
-        if (!dead && p >= g0 && p < g0 + 8) { // this lane's group holds the site: a -> c
-            const int e = p - g0;
-            const uint32_t m = (e & 1) ? 0xffff0000u : 0x0000ffffu;
-            const uint32_t cv = (e & 1) ? (c << 16) : c;
-            if ((e >> 1) == 0) U0 = (U0 & ~m) | cv;
-            else if ((e >> 1) == 1) U1 = (U1 & ~m) | cv;
-            else if ((e >> 1) == 2) U2 = (U2 & ~m) | cv;
-            else U3 = (U3 & ~m) | cv;
+        { // the lane whose group holds the site: a -> c.  Branch-free: the half-word mask and the value are wave-uniform
+          // (p is), only "is it my dword" differs by lane -- as nested ifs this was ~90 instructions of exec-mask juggling
+            const int e = p - g0; // (0..7 in the one lane that holds the site)
+            const uint32_t hm = (p & 1) ? 0xffff0000u : 0x0000ffffu, cv = (p & 1) ? (c << 16) : c;
+            const uint32_t sel = (!dead && e >= 0 && e < 8) ? hm : 0u; // 0: nothing changes in this lane
+            const int dw = e >> 1;
+            const uint32_t m0 = dw == 0 ? sel : 0u, m1 = dw == 1 ? sel : 0u, m2 = dw == 2 ? sel : 0u, m3 = dw == 3 ? sel : 0u;
+            U0 = (U0 & ~m0) | (cv & m0);
+            U1 = (U1 & ~m1) | (cv & m1);
+            U2 = (U2 & ~m2) | (cv & m2);
+            U3 = (U3 & ~m3) | (cv & m3);
         }
         uint32_t S0, S1, S2, S3; // the group as it looks when every slot comes from s positions to the right
         if (s == 1) {
@@ -1625,7 +1632,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_skip(ApplySkipParams Q) {
         uint32_t base = 0;
         if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (maybe) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(t, len);
+        if (maybe) s_list[base + bits_below_lane(m)] = make_uint2(t, len);
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
@@ -2732,7 +2739,7 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
             uint32_t base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (mb) s_list[base + __popcll(m & lanemask_lt(lane))] = make_uint2(ch * chunk + j * NT + threadIdx.x, len[j]);
+            if (mb) s_list[base + bits_below_lane(m)] = make_uint2(ch * chunk + j * NT + threadIdx.x, len[j]);
         }
         __syncthreads();
         const uint32_t n = s_n;
