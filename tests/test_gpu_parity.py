@@ -162,11 +162,35 @@ def test_many_tiles_retile_and_table_growth():
                  {"fuse_select": 0}, {"cand_rebuild_every": 1}, {"cand_rebuild_every": 100000, "check_interval": 8}, {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
                  {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16},
                  {"fused": 0}, {"fused": 1, "check_interval": 3}, {"cand_target": 64, "check_interval": 4}, {"cas_first": 1}, {"table_load_pct": 70, "table_grow_x": 2},
-                 {"dense_table": 1}, {"dense_table": 1, "check_interval": 3, "cand_target": 64}, {"dense_table": 1, "fused": 0}, {"dense_table": 1, "cand_argmax": 0}):
+                 {"dense_table": 1}, {"dense_table": 1, "check_interval": 3, "cand_target": 64}, {"dense_table": 1, "fused": 0}, {"dense_table": 1, "cand_argmax": 0},
+                 {"full_wpb": 4}, {"full_wpb": 8}, {"full_wpb": 16}, {"full_wpb": 16, "full_skip_blocks": 3}, {"full_wpb": 8, "dense_worklist": 1, "check_interval": 5},
+                 {"hist": 0}, {"hist": 0, "split": 0}, {"split": 0}, {"split": 0, "apply_blocks": 5, "check_interval": 3}):
         v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
         assert (v3, m3) == (exp_vocab, exp_merges), opts
     assert s1["scan_skip_launches"] > 0 and s1["scan_skip_tiles_read"] < s1["scan_skip_launches"] * s1["n_tiles"]
     assert s1["tokens_initial"] - s1["tokens_now"] == s2["tokens_initial"] - s2["tokens_now"]
+
+
+def test_streaming_form_across_the_direct_store_limit():
+    """The streaming launch keeps a workgroup's deltas in a direct-indexed LDS store while at most 512 tokens exist and in the
+    hashed aggregator afterwards: a corpus over four letters stays dense (more sites than tiles) for hundreds of merges, so
+    the switch happens inside the streaming phase; forced never-split as well.  Wide workgroups on the pooled layout too."""
+    from yet_another_bpe import _native
+
+    rng = np.random.default_rng(11)
+    n_words = 120_000
+    lens = rng.integers(2, 14, size=n_words)
+    off = np.zeros(n_words + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    flat = rng.choice(np.frombuffer(b"abcd", dtype=np.uint8), size=int(off[-1]), p=[0.4, 0.3, 0.2, 0.1]).astype(np.uint8)
+    base = helpers.base_tokens(SP)
+    exp_vocab, exp_merges = oracle.train_flat(flat, off, 257 + 420, 1, SP)
+    for opts in ({}, {"split": 0}, {"split": 0, "hist": 0}, {"split": 0, "check_interval": 7}, {"split": 1, "full_wpb": 16}):
+        v, m, st = _native.train_words(flat, off, None, base, 420, 1, options={"verify": 1, **opts}, want_stats=True)
+        assert (v, m) == (exp_vocab, exp_merges), opts
+    for opts in ({"full_wpb": 16}, {"full_wpb": 8, "split": 1}):
+        v, m = _native.train_words(flat, off, None, base, 420, 1, dedup=True, options={"verify": 1, **opts})
+        assert (v, m) == (exp_vocab, exp_merges), opts
 
 
 def test_weighted_layout_split_forms():
