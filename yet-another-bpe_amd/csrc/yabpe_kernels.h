@@ -1030,10 +1030,11 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
 
 // Rewrites one tile that contains at least one candidate site: pair-count deltas, drop bitmap, compaction,
 // write-back.  Work is proportional to the number of sites.  Returns false when nothing changed.
-template <bool WEIGHTED, class AggV, bool HIST = false>
+// HAVE_MASKS: the caller has the candidate masks of the two segments already (match_mask8): pmA, pmB.
+template <bool WEIGHTED, class AggV, bool HIST = false, bool HAVE_MASKS = false>
 __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
                                           uint32_t na, uint32_t nb, unsigned long long &wave_sites,
-                                          unsigned long long &wave_freed) {
+                                          unsigned long long &wave_freed, uint32_t pmA = 0u, uint32_t pmB = 0u) {
     const ApplyParams &P = C.P;
     DevState *st = C.st;
     const uint32_t a = C.a, b = C.b, c = C.c, mk = C.mk, self = C.self;
@@ -1048,8 +1049,8 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
 #endif
     uint32_t mA, mB; // site masks of the two segments
     if (a != b) {
-        mA = match_mask8(r.va, na, mk);
-        mB = match_mask8(r.vb, nb, mk);
+        mA = HAVE_MASKS ? pmA : match_mask8(r.va, na, mk);
+        mB = HAVE_MASKS ? pmB : match_mask8(r.vb, nb, mk);
         if (!WEIGHTED) {
             const uint32_t mine = mA | (mB << 8);
             const unsigned long long holders = __ballot(mine != 0);
@@ -1182,16 +1183,23 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
         if (first_drop > 0) first_drop -= 1;
     }
     {
-        uint32_t oA = (inc & 0xffffu) - kA, oB = (tot & 0xffffu) + (inc >> 16) - kB;
+        // (this scatter was 144 of the rewrite's ~265 VALU instructions per tile, and the streaming phase is VALU-bound:
+        // an element's offset is one and + one popcount-with-add instead of a running sum, the token goes out as it lies
+        // in its dword, and the few sites get their merged token in a second, short step)
+        const uint32_t oA = (inc & 0xffffu) - kA, oB = (tot & 0xffffu) + (inc >> 16) - kB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if ((keepA >> j) & 1u) outb[oA] = (uint16_t)(((mA >> j) & 1u) ? c : elem16(r.va, j));
-            oA += (keepA >> j) & 1u;
+        for (int j = 0; j < 8; ++j)
+            if ((keepA >> j) & 1u) outb[oA + __popc(keepA & ((1u << j) - 1u))] = (uint16_t)elem16(r.va, j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((keepB >> j) & 1u) outb[oB + __popc(keepB & ((1u << j) - 1u))] = (uint16_t)elem16(r.vb, j);
+        for (uint32_t sm = mA; __any(sm != 0u); sm &= sm - 1u) { // (a site's a becomes c -- unless its whole word leaves)
+            const uint32_t lb = sm & (0u - sm);
+            if (lb & keepA) outb[oA + __popc(keepA & (lb - 1u))] = (uint16_t)c;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if ((keepB >> j) & 1u) outb[oB] = (uint16_t)(((mB >> j) & 1u) ? c : elem16(r.vb, j));
-            oB += (keepB >> j) & 1u;
+        for (uint32_t sm = mB; __any(sm != 0u); sm &= sm - 1u) {
+            const uint32_t lb = sm & (0u - sm);
+            if (lb & keepB) outb[oB + __popc(keepB & (lb - 1u))] = (uint16_t)c;
         }
     }
     const uint32_t pad_end = (new_len + 7u) & ~7u;
@@ -2595,11 +2603,14 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
             const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
             const uint32_t na = next_lane(r.va.x, b0);
             const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+            // (nearly every tile of this phase holds the pair: the per-lane candidate masks are computed once, here, and
+            // handed to the rewrite -- a cheaper any-test first would be paid on top of them in almost every tile)
+            const uint32_t pmA = match_mask8(r.va, na, mk), pmB = match_mask8(r.vb, nb, mk);
+            if (!__any((pmA | pmB) != 0u)) continue;
 #ifdef YB_PROFILE_SLOW // [5]: from the end of one rewrite to the start of the next (the wait for the tile, the match)
             if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
 #endif
-            slow_tile<WEIGHTED, AggV, HIST>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
+            slow_tile<WEIGHTED, AggV, HIST, true>(C, W, tile, len, r, na, nb, wave_sites, wave_freed, pmA, pmB);
 #ifdef YB_PROFILE_SLOW
             t_end = __builtin_readcyclecounter();
 #endif
