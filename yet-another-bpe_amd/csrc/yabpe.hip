@@ -1432,7 +1432,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 // left -- and the whole stream fits one round of such workgroups -- else 8)
                 int64_t wpb_opt = optv(c, "full_wpb", 0);
                 if (wpb_opt <= 0)
-                    wpb_opt = (c->st_host->best_count <= 20ull * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
+                    wpb_opt = (c->st_host->best_count <= (unsigned long long)optv(c, "wide_sites_per_cu", 20) * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
                 const uint32_t nw = !full ? (uint32_t)WPB : (wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB);
                 const uint32_t nt = nw * 64u;
                 const uint32_t n256 = (c->n_tiles + nt - 1) / nt;
@@ -1447,6 +1447,9 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
                                   scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, R, fuse_params(full ? scan_grid : 0u)};
                 if (!full) SQ.F.ticket = nullptr;  // (can_fuse() never asks for this form)
+                // (a workgroup of 16 waves collects twice the deltas of one of 8: the small aggregator grows with it, or its
+                // probe windows fill and updates go to the table one by one from inside the candidate loop)
+                if (nw >= 16 && SQ.A.agg_mask == (uint32_t)AGG_N / 4 - 1) SQ.A.agg_mask = (uint32_t)(AGG_N / std::max<int64_t>(1, optv(c, "agg_wide_div", 2))) - 1;
                 c->blk_used = std::max(c->blk_used, scan_grid);
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
                 const bool inl = !c->weighted && optv(c, "inline_single", 1);
