@@ -494,6 +494,7 @@ __device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevS
             if (at < t.sink_cap) t.sink_rec[at] = DeltaRec{k[q], 0u, v[q]};
             ++at;
         }
+        __syncthreads(); // (s_wtot / s_sbase are read above: the direct-indexed store calls this once per role, back to back)
         return;
     }
     if (t.dense) { // direct-indexed counts: every delta is ONE atomic, nothing to look up first
