@@ -1457,11 +1457,11 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
 #define YB_LAUNCH_FULL(NW_)                                                                                                   \
     do {                                                                                                                      \
         if (c->weighted)                                                                                                      \
-            hipLaunchKernelGGL((k_scan_skip<false, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);          \
+            hipLaunchKernelGGL((k_scan_skip<false, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
         else if (inl)                                                                                                         \
-            hipLaunchKernelGGL((k_scan_skip<true, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);          \
+            hipLaunchKernelGGL((k_scan_skip<true, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_scan_skip<false, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, SQ);         \
+            hipLaunchKernelGGL((k_scan_skip<false, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);         \
     } while (0)
                     if (nw == 16) YB_LAUNCH_FULL(16);
                     else if (nw == 8) YB_LAUNCH_FULL(8);
@@ -1469,9 +1469,9 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
 #undef YB_LAUNCH_FULL
                     skip_slow = true;
                 } else if (inl) {
-                    hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                    hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);
                 } else {
-                    hipLaunchKernelGGL((k_scan_skip<false, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, SQ);
+                    hipLaunchKernelGGL((k_scan_skip<false, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);
                 }
                 c->scan_skip_launches++;
             } else {

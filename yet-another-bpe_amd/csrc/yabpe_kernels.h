@@ -2665,7 +2665,7 @@ struct ScanSkipParams {
 // matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
 // already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
 template <bool INLINE, bool FULL, bool WEIGHTED, int NW>
-__device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // false: stop flag set, nothing done (grid-uniform)
+__device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipParams &Q) { // false: stop flag set, nothing done (grid-uniform)
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     constexpr bool REWRITES = INLINE || FULL;
     constexpr int NT = NW * 64;                   // threads of the workgroup (NW waves)
@@ -2680,7 +2680,6 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? NW : 1];
     __shared__ unsigned long long s_cnt[2];
     const ScanParams &P = Q.S;
-    DevState *st = P.st;
     YB_SCAN_STAMP(0);
     // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
     const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c, st_new = st->c_is_new;
@@ -2903,8 +2902,11 @@ __device__ __forceinline__ bool scan_skip_block(const ScanSkipParams &Q) { // fa
     return true;
 }
 template <bool INLINE, bool FULL, bool WEIGHTED, int NW = WPB>
-__global__ __launch_bounds__(NW * 64, FULL ? 16 / NW : 1) void k_scan_skip(ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 16 waves per CU)
-    if (!scan_skip_block<INLINE, FULL, WEIGHTED, NW>(Q)) return;
+// st (= Q.S.st) is a kernel argument of its own, the FIRST one: the library is built with kernel-argument preload for two
+// dwords (Makefile), so the pointer is in SGPRs when the wave starts and the read of the merge record does not have to wait
+// for the argument segment first -- one dependent trip less in front of every merge.
+__global__ __launch_bounds__(NW * 64, FULL ? 16 / NW : 1) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 16 waves per CU)
+    if (!scan_skip_block<INLINE, FULL, WEIGHTED, NW>(st, Q)) return;
     if constexpr (FULL) fused_select_tail(Q.F);
 }
 
