@@ -191,8 +191,12 @@ struct yabpe_ctx {
     uint8_t *xsend = nullptr, *xrecv = nullptr;  // [DeltaHdr | xcap DeltaRec] of this rank / of every rank
     uint64_t exchange_growths = 0;  // times the exchange buffers had to grow (a merge produced more records than fit)
     uint64_t exchange_max_records = 0;  // largest record count of one rank seen at a batch end
-    uint32_t xcap = 0;      // records per rank per exchange
+    uint32_t xcap = 0;      // records per rank the exchange buffers hold
     uint64_t xstride = 0;   // bytes per rank buffer
+    uint32_t xeff = 0;      // records per rank an exchange TRANSMITS (<= xcap): follows what the merges really produce, so
+                            // that an all-gather moves a few dozen KiB per rank late in a job, not the whole 256 KiB buffer
+    uint64_t xeff_sum = 0;  // (statistics: sum of xeff over the exchanges)
+    uint32_t xseen[4] = {0, 0, 0, 0};  // the largest record counts of the last four batches
     uint64_t exchanges = 0;
 };
 
@@ -808,6 +812,7 @@ int comm_buffers(yabpe_ctx *c, uint32_t cap) {
     dfree(c->xrecv);
     c->xsend = c->xrecv = nullptr;
     c->xcap = cap;
+    c->xeff = cap;
     c->xstride = 16 + (uint64_t)cap * sizeof(DeltaRec);
     TRY(dmalloc(c, &c->xsend, c->xstride));
     TRY(dmalloc(c, &c->xrecv, c->xstride * c->n_ranks));
@@ -1279,6 +1284,9 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->cand_rebuilds = c->cand_rescans = 0;
     c->fused_launches = 0;
     c->exchanges = 0;
+    c->xeff = c->xcap;  // (a new job starts with whole buffers: its first merges are its densest)
+    c->xseen[0] = c->xseen[1] = c->xseen[2] = c->xseen[3] = 0;
+    c->xeff_sum = 0;
     c->exchange_growths = 0;
     c->exchange_max_records = 0;
     if (c->blk_read) HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
@@ -1363,7 +1371,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         out_table = PairTable{};
         out_table.sink_hdr = reinterpret_cast<DeltaHdr *>(c->xsend);
         out_table.sink_rec = reinterpret_cast<DeltaRec *>(c->xsend + 16);
-        out_table.sink_cap = c->xcap;
+        out_table.sink_cap = c->xeff;  // (what this exchange transmits: a rank with more records than that reports it by its count)
     }
     const bool fuse_kernel = fuse && !c->multi;  // the apply launch itself ends with the selection
     if (ev) {
@@ -1507,13 +1515,15 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         // Per merge: the apply launch above left this rank's updates as [header | records] in its send buffer (the
         // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every
         // rank's records to the replica and -- fused form -- selects the next merge in its last workgroup.
-        TRY(comm_allgather(c, c->xsend, c->xrecv, c->xstride));
-        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xcap, c->xstride, c->table, c->st, FuseParams{}};
+        const uint64_t xbytes = 16 + (uint64_t)c->xeff * sizeof(DeltaRec);  // [header | xeff records] per rank, packed at that stride
+        TRY(comm_allgather(c, c->xsend, c->xrecv, xbytes));
+        c->xeff_sum += c->xeff;
+        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xeff, xbytes, c->table, c->st, FuseParams{}};
         if (fuse) {
             DA.F.ticket = c->sel_ticket;
             DA.F.sel = select_params(c, rec_base, 0u, c->blk_used);
         }
-        hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xcap, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
+        hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xeff, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
         c->exchanges++;
     }
     if (fuse) {
@@ -1704,12 +1714,22 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         TRY(state_pull(c));
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
         if (h->done || h->halt) c->pending = false;          // the last selection of the batch did not select
-        if (c->multi && c->xrecv) {  // (measurement: how full the exchange buffers are -- the last exchange of the batch)
-            for (int r = 0; r < c->n_ranks; ++r) {
-                unsigned long long cnt = 0;
-                HIPCHK(c, hipMemcpy(&cnt, c->xrecv + (uint64_t)r * c->xstride, 8, hipMemcpyDeviceToHost));
-                c->exchange_max_records = std::max<uint64_t>(c->exchange_max_records, cnt);
+        if (c->multi && c->xrecv) {
+            // what the exchanges of this batch really carried (the largest count of any rank, the same number on every rank):
+            // the next batch transmits twice that plus a margin, never less than 2,048 records, never more than the buffers hold
+            const uint32_t seen = h->xmax;
+            c->exchange_max_records = std::max<uint64_t>(c->exchange_max_records, seen);
+            c->xseen[3] = c->xseen[2]; c->xseen[2] = c->xseen[1]; c->xseen[1] = c->xseen[0]; c->xseen[0] = seen;
+            if (optv(c, "delta_adapt", 1) && h->halt != HALT_DELTA_FULL && h->iter - rec_base >= 4 * check) {
+                // (an overflow costs a recount of the whole stream: twice the largest count of the last four batches, and
+                // nothing shrinks during the first batches of a job, whose merges differ most from one another)
+                const uint64_t recent = std::max(std::max(c->xseen[0], c->xseen[1]), std::max(c->xseen[2], c->xseen[3]));
+                const uint64_t want = ((2ull * recent + 1024ull + 1023ull) / 1024ull) * 1024ull;
+                c->xeff = (uint32_t)std::min<uint64_t>(c->xcap, std::max<uint64_t>(want, std::min<uint64_t>(2048, c->xcap)));
             }
+            if (optv(c, "trace_exchange", 0) && c->rank == 0) fprintf(stderr, "[yabpe] exchange: merges %u records<= %u next %u halt %u\n", h->iter - rec_base, seen, c->xeff, h->halt);
+            HIPCHK(c, hipMemsetAsync(&c->st->xmax, 0, sizeof(uint32_t), c->stream));
+            h->xmax = 0;
         }
         if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
             unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
@@ -1732,8 +1752,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 const bool delta_full = h->halt == HALT_DELTA_FULL;
                 h->halt = 0; h->halt_req = 0;
                 TRY(state_push(c));
-                if (delta_full) {  // a merge produced more records on some rank than its send buffer holds: 4x for everybody
-                    TRY(comm_buffers(c, c->xcap * 4));
+                if (delta_full) {  // a merge produced more records on some rank than an exchange transmits: 4x for everybody
+                    if (c->xeff < c->xcap) {
+                        c->xeff = (uint32_t)std::min<uint64_t>(c->xcap, 4ull * c->xeff);  // (the buffers hold more: no reallocation)
+                    } else {
+                        TRY(comm_buffers(c, c->xcap * 4));
+                    }
                     c->exchange_growths++;
                 }
                 TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
@@ -1900,7 +1924,7 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.cand_rescans = c->cand_rescans;
     c->stats.fused_launches = c->fused_launches;
     c->stats.exchanges = c->exchanges;
-    c->stats.exchange_bytes = c->multi ? c->xstride * (uint64_t)c->n_ranks : 0;
+    c->stats.exchange_bytes = (c->multi && c->exchanges) ? (16 + (c->xeff_sum / c->exchanges) * sizeof(DeltaRec)) * (uint64_t)c->n_ranks : 0;  // (mean over the exchanges)
     c->stats.exchange_cap_records = c->xcap;
     c->stats.exchange_growths = c->exchange_growths;
     c->stats.exchange_max_records = c->exchange_max_records;

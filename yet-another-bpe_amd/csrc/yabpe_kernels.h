@@ -65,7 +65,7 @@ struct DevState {
     unsigned long long best_count; // count of the merge being applied
     uint32_t chunk_next[8];        // k_apply_skip: dynamic chunk queues (sharded 8 ways), reset by k_select
     uint32_t work_total;           // dense worklist: items appended by k_scan_skip this merge (reset by k_select)
-    uint32_t pad1;
+    uint32_t xmax;                 // multi-GPU: the largest record count any rank has sent since the host cleared this (k_delta_apply)
 };
 
 // multi-GPU exchange records: what a rank's apply pass sends to the others (see k_delta_apply)
@@ -3021,6 +3021,7 @@ __global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
         if (j == 0) { // every rank reads every header: all of them stop at the same merge
             if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
             else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
+            atomicMax(&P.st->xmax, (uint32_t)min(n, 0xffffffffull)); // (every rank sees every header: the same value everywhere)
         }
         if (j < n && j < P.cap) {
             const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
