@@ -1523,7 +1523,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             DA.F.ticket = c->sel_ticket;
             DA.F.sel = select_params(c, rec_base, 0u, c->blk_used);
         }
-        hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xeff, BLOCK)), dim3(BLOCK), 0, c->stream, DA);
+        hipLaunchKernelGGL(k_delta_apply, dim3(cdiv64((uint64_t)c->n_ranks * c->xeff, DELTA_RPW)), dim3(BLOCK), 0, c->stream, DA);
         c->exchanges++;
     }
     if (fuse) {

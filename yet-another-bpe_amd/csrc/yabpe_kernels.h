@@ -3011,23 +3011,38 @@ struct DeltaApplyParams {
     DevState *st;
     FuseParams F;        // ticket != NULL: the workgroup that finishes last selects the next merge (one launch fewer per merge)
 };
+// Every rank's records name the same hot pairs over and over (one record per WORKGROUP of the sender that saw the pair, times
+// the number of ranks), and same-address atomics are served one per 12.5 ns: added to the table record by record they would
+// queue for tens of microseconds at 8 ranks.  A workgroup therefore sums its DELTA_RPW records in the LDS aggregator first
+// and flushes that (the same flush as the apply launches': batched key loads, candidate notes).
+constexpr int DELTA_RPW = 4 * BLOCK; // records per workgroup
 __global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ unsigned long long s_vals[AGG_N];
     if (P.st->done | P.st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
-    const unsigned long long idx = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t r = (uint32_t)(idx / P.cap), j = (uint32_t)(idx % P.cap);
-    if (r < P.n_ranks) {
-        const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
-        const unsigned long long n = h->count;
-        if (j == 0) { // every rank reads every header: all of them stop at the same merge
-            if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
-            else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
-            atomicMax(&P.st->xmax, (uint32_t)min(n, 0xffffffffull)); // (every rank sees every header: the same value everywhere)
-        }
-        if (j < n && j < P.cap) {
-            const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
-            gt_add(P.table, P.st, rec[j].key, rec[j].delta);
+    const Agg<unsigned long long> agg{s_keys, s_vals, (uint32_t)AGG_N - 1u};
+    agg_init(agg);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DELTA_RPW / BLOCK; ++q) {
+        const unsigned long long idx = (unsigned long long)blockIdx.x * DELTA_RPW + (unsigned long long)q * BLOCK + threadIdx.x;
+        const uint32_t r = (uint32_t)(idx / P.cap), j = (uint32_t)(idx % P.cap);
+        if (r < P.n_ranks) {
+            const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
+            const unsigned long long n = h->count;
+            if (j == 0) { // every rank reads every header: all of them stop at the same merge
+                if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
+                else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
+                atomicMax(&P.st->xmax, (uint32_t)min(n, 0xffffffffull)); // (every rank sees every header: the same value everywhere)
+            }
+            if (j < n && j < P.cap) {
+                const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
+                agg_add(agg, P.table, P.st, rec[j].key, rec[j].delta);
+            }
         }
     }
+    __syncthreads();
+    agg_flush<unsigned long long, BLOCK>(agg, P.table, P.st);
     fused_select_tail(P.F);
 }
 
