@@ -180,6 +180,10 @@ def gpu_sharded(rank, world, dist, scenario):
         flat, off = synth.generate(synth.SynthSpec(24 << 20, 100_000, 13, bytes(range(256)), False))
         freq, merges = None, 2000
         opts = {}
+    elif scenario == "synthetic_tight_exchange":  # the exchange transmits LESS than merges need (half the recent maximum): overflows
+        flat, off = synth.generate(synth.SynthSpec(6 << 20, 30_000, 17, bytes(range(256)), False))  # that grow it again without reallocating
+        freq, merges = None, 600
+        opts.update({"check_interval": 4, "delta_headroom_pct": 50, "delta_margin": 0, "delta_floor": 8, "delta_granule": 8})
     elif scenario == "long_words":
         words = [b" " * 900, b"ab" * 700, b"xyz" * 50, b"abcabc", b"  ", b"aaa"] * 3 + [b"hello world"] * 5
         flat, off = helpers.flatten(words)

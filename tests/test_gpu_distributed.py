@@ -24,18 +24,21 @@ def _expect(scenario):
     if scenario == "synthetic_medium":
         flat, off = synth.generate(synth.SynthSpec(24 << 20, 100_000, 13, bytes(range(256)), False))
         return oracle.train_flat(flat, off, 257 + 2000, 1, SP)[1]
+    if scenario == "synthetic_tight_exchange":
+        flat, off = synth.generate(synth.SynthSpec(6 << 20, 30_000, 17, bytes(range(256)), False))
+        return oracle.train_flat(flat, off, 257 + 600, 1, SP)[1]
     words = [b" " * 900, b"ab" * 700, b"xyz" * 50, b"abcabc", b"  ", b"aaa"] * 3 + [b"hello world"] * 5
     return oracle.merge_loop(words, 257 + 120, 1, SP)[1]
 
 
-@pytest.mark.parametrize("scenario", ["corpus_en_flat", "corpus_en_weighted", "synthetic_small_buffers", "synthetic_medium", "long_words"])
+@pytest.mark.parametrize("scenario", ["corpus_en_flat", "corpus_en_weighted", "synthetic_small_buffers", "synthetic_medium", "synthetic_tight_exchange", "long_words"])
 def test_two_ranks_one_gpu(scenario):
     exp = _expect(scenario)
     outs = dist_workers.spawn(dist_workers.gpu_sharded, 2, scenario, timeout=900)
     for merges, n_words, rebuilds, retiles in outs:
         assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp
     assert outs[0][1] > 0 and outs[1][1] > 0  # both ranks held words
-    if scenario == "synthetic_small_buffers":
+    if scenario in ("synthetic_small_buffers", "synthetic_tight_exchange"):
         assert outs[0][2] >= 1  # the overflow recovery (global recount) ran
 
 

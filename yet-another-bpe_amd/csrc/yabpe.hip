@@ -1724,8 +1724,10 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 // (an overflow costs a recount of the whole stream: twice the largest count of the last four batches, and
                 // nothing shrinks during the first batches of a job, whose merges differ most from one another)
                 const uint64_t recent = std::max(std::max(c->xseen[0], c->xseen[1]), std::max(c->xseen[2], c->xseen[3]));
-                const uint64_t want = ((2ull * recent + 1024ull + 1023ull) / 1024ull) * 1024ull;
-                c->xeff = (uint32_t)std::min<uint64_t>(c->xcap, std::max<uint64_t>(want, std::min<uint64_t>(2048, c->xcap)));
+                const uint64_t gran = (uint64_t)std::max<int64_t>(1, optv(c, "delta_granule", 1024));
+                const uint64_t raw = recent * (uint64_t)std::max<int64_t>(1, optv(c, "delta_headroom_pct", 200)) / 100ull + (uint64_t)std::max<int64_t>(0, optv(c, "delta_margin", 1024));
+                const uint64_t want = ((raw + gran - 1) / gran) * gran;
+                c->xeff = (uint32_t)std::min<uint64_t>(c->xcap, std::max<uint64_t>(want, std::min<uint64_t>((uint64_t)std::max<int64_t>(1, optv(c, "delta_floor", 2048)), c->xcap)));
             }
             if (optv(c, "trace_exchange", 0) && c->rank == 0) fprintf(stderr, "[yabpe] exchange: merges %u records<= %u next %u halt %u\n", h->iter - rec_base, seen, c->xeff, h->halt);
             HIPCHK(c, hipMemsetAsync(&c->st->xmax, 0, sizeof(uint32_t), c->stream));
