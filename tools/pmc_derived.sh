@@ -1,8 +1,10 @@
 #!/bin/bash
 # Dev tool: rocprofv3's derived metrics (VALUBusy, LdsUtil, latencies, stalls, occupancy ...) for the per-merge kernels, a few
 # per pass.   tools/pmc_derived.sh OUT_DIR MERGES   -> OUT_DIR/pmc_derived.txt   (mean per kernel name over working dispatches)
+# (every launch is collected: 20,000 merges take minutes per pass and the latency groups longer still -- keep MERGES small, and do
+# not pipe the output into tail: a pass that prints nothing for 7 minutes is taken for hung on the gpurun boxes)
 OUT=${1:-gpurun_out/pmc_derived}
-MERGES=${2:-24}
+MERGES=${2:-3000}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -10,6 +12,7 @@ i=0
 for G in "VALUBusy SALUBusy GRBM_GUI_ACTIVE" "LdsUtil LDSBankConflict LdsLatency" "VmemLatency SmemLatency InstrFetchLatency" "MemUnitStalled OccupancyPercent MeanOccupancyPerCU" "SIMD_UTILIZATION VALUUtilization SerializedAtomicRatio"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $G --kernel-include-regex "k_apply|k_scan_skip" --output-format csv -d "$ROOT/$OUT/raw$i" -- python3 "$ROOT/tools/quick_job.py" --merges $MERGES --runs 1 --sample 0 > "$ROOT/$OUT/run$i.log" 2>&1 || echo "group $i ($G) failed"
+  echo "pass $i ($G) done" | tee -a "$ROOT/$OUT/progress.txt"
 done
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
