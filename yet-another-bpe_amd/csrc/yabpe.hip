@@ -1667,9 +1667,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         if (c->split_mode && optv(c, "skip_index", 1)) {
             // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
             // (rewrites only ever ADD bits: every merged site leaves up to two new pairs and three stale ones behind)
-            const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 4096));
+            const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 16384));
             const uint64_t merged_since = c->sig_tokens_at_build > h->tokens_now ? c->sig_tokens_at_build - h->tokens_now : 0;
-            const bool stale = merged_since * 100 > c->sig_tokens_at_build * (uint64_t)optv(c, "sig_rebuild_pct", 12);
+            const bool stale = merged_since * 100 > c->sig_tokens_at_build * (uint64_t)optv(c, "sig_rebuild_pct", 20);
             if (!c->sig_valid || i - c->sig_built_at >= every || stale) {
                 TRY(build_signatures(c));
                 c->sig_valid = true;
