@@ -1446,14 +1446,17 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 const uint32_t n256 = (c->n_tiles + nt - 1) / nt;
                 const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)))
                                              : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
-                const uint32_t kt = std::min<uint32_t>((uint32_t)scan_kt_max((int)nw), std::max<uint32_t>(1, (n256 + target - 1) / target));
-                const uint32_t chunk = nt * kt;
+                // tiles per workgroup: what fills `target` workgroups, in whole waves of signature tests, at most kt_max per thread
+                (void)n256;
+                const uint32_t ktm = (uint32_t)scan_kt_max((int)nw);
+                const uint32_t chunk = std::min<uint32_t>(nt * ktm, std::max<uint32_t>(64u, (uint32_t)(((uint64_t)(c->n_tiles + target - 1) / target + 63u) / 64u * 64u)));
+                const uint32_t kt = (chunk + nt - 1) / nt;
                 const uint32_t n_chunks = (c->n_tiles + chunk - 1) / chunk;
                 scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n_chunks, target), MAX_LISTS));
                 seg = chunk * ((n_chunks + scan_grid - 1) / scan_grid);
                 TRY(ensure_worklist(c, scan_grid, seg));
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
-                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, R, fuse_params(full ? scan_grid : 0u)};
+                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, chunk, R, fuse_params(full ? scan_grid : 0u)};
                 if (!full) SQ.F.ticket = nullptr;  // (can_fuse() never asks for this form)
                 // (a workgroup of 16 waves collects twice the deltas of one of 8: the small aggregator grows with it, or its
                 // probe windows fill and updates go to the table one by one from inside the candidate loop)

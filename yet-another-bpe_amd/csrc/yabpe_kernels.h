@@ -2653,7 +2653,9 @@ struct ScanSkipParams {
     uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
     uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
     uint32_t dense_cap;
-    uint32_t kt;                  // signature tests per thread: a workgroup takes SCAN_CHUNK * kt consecutive tiles at a time
+    uint32_t kt;                  // signature tests per thread: a workgroup takes `chunk` <= threads * kt consecutive tiles at a time
+    uint32_t chunk;               // ... (a multiple of 64; smaller than the workgroup when there are few tiles: a stream of 8,000 tiles
+                                  // -- pooled words -- still spreads over 125 workgroups whose waves ALL rewrite matched tiles)
     RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
     FuseParams F;                 // FULL form: the workgroup that finishes last selects the next merge (ticket != NULL)
 };
@@ -2725,18 +2727,19 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
     uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t kt = Q.kt;
-    const uint32_t chunk = NT * kt;
+    const uint32_t chunk = Q.chunk;
     const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
     for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
         // all of this thread's signature words are requested before the first one is looked at
         uint32_t len[KTM];
         bool maybe[KTM];
+        const uint32_t t_end = min(P.n_tiles, ch * chunk + chunk);
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
             const uint32_t t = ch * chunk + j * NT + threadIdx.x;
             len[j] = 0;
             maybe[j] = false;
-            if (j < kt && t < P.n_tiles) {
+            if (j < kt && t < t_end) { // (t_end: the end of this workgroup's run of tiles, or of the stream)
                 len[j] = P.tile_len[t];
                 maybe[j] = probe.maybe(t);
             }
