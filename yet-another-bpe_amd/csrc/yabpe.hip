@@ -1443,11 +1443,9 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                     wpb_opt = (c->st_host->best_count <= (unsigned long long)optv(c, "wide_sites_per_cu", 20) * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
                 const uint32_t nw = !full ? (uint32_t)WPB : (wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB);
                 const uint32_t nt = nw * 64u;
-                const uint32_t n256 = (c->n_tiles + nt - 1) / nt;
                 const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)))
                                              : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
                 // tiles per workgroup: what fills `target` workgroups, in whole waves of signature tests, at most kt_max per thread
-                (void)n256;
                 const uint32_t ktm = (uint32_t)scan_kt_max((int)nw);
                 const uint32_t chunk = std::min<uint32_t>(nt * ktm, std::max<uint32_t>(64u, (uint32_t)(((uint64_t)(c->n_tiles + target - 1) / target + 63u) / 64u * 64u)));
                 const uint32_t kt = (chunk + nt - 1) / nt;
