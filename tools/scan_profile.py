@@ -18,7 +18,7 @@ with _native.Context() as g:
     pb, po, nw, nb = g.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
     with _native.Context() as ctx:
         ctx.set_option("full_wpb", WPB)
-        ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw)
+        ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw, dedup=bool(int(os.environ.get("DEDUP", "0"))))  # DEDUP=1: the pooled layout
         done = 0
         for m in merges:
             ctx.train(m - done, 1); done = m
@@ -27,9 +27,9 @@ with _native.Context() as g:
             _native.lib().yabpe_debug_scan_profile(ctypes.c_void_p(out.ctypes.data), ctypes.c_uint32(NB))
             p = out.reshape(NB, 8).astype(np.int64)
             nt = 64 * WPB
-            n256 = (st["n_tiles"] + nt - 1) // nt; target = 256 * 16 // WPB  # (full_skip_blocks: 16 waves per CU)
-            kt = min(2 if WPB >= 16 else 4, max(1, -(-n256 // target)))
-            n_scan = min(-(-st["n_tiles"] // (nt * kt)), target)
+            target = 256 * 16 // WPB  # (full_skip_blocks: 16 waves per CU)
+            chunk = min(nt * (2 if WPB >= 16 else 4), max(64, (-(-st["n_tiles"] // target) + 63) // 64 * 64))  # as the host sizes it
+            n_scan = min(-(-st["n_tiles"] // chunk), target)
             recent = p[:, 7].max() - 30000  # stamps older than 300 us belong to earlier launches
             scan = p[:n_scan]; rank = p[n_scan:]; rank = rank[rank[:, 0] > recent]
             scan = scan[scan[:, 0] > recent]

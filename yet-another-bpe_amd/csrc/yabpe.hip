@@ -1461,11 +1461,13 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 if (nw >= 16 && SQ.A.agg_mask == (uint32_t)AGG_N / 4 - 1) SQ.A.agg_mask = (uint32_t)(AGG_N / std::max<int64_t>(1, optv(c, "agg_wide_div", 2))) - 1;
                 c->blk_used = std::max(c->blk_used, scan_grid);
                 const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
-                const bool inl = !c->weighted && optv(c, "inline_single", 1);
+                const bool inl = optv(c, "inline_single", 1);  // (non-FULL forms: flat layout only, below)
                 if (full) {
 #define YB_LAUNCH_FULL(NW_)                                                                                                   \
     do {                                                                                                                      \
-        if (c->weighted)                                                                                                      \
+        if (c->weighted && inl)                                                                                               \
+            hipLaunchKernelGGL((k_scan_skip<true, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);           \
+        else if (c->weighted)                                                                                                 \
             hipLaunchKernelGGL((k_scan_skip<false, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
         else if (inl)                                                                                                         \
             hipLaunchKernelGGL((k_scan_skip<true, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
@@ -1477,7 +1479,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                     else YB_LAUNCH_FULL(WPB);
 #undef YB_LAUNCH_FULL
                     skip_slow = true;
-                } else if (inl) {
+                } else if (inl && !c->weighted) {
                     hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);
                 } else {
                     hipLaunchKernelGGL((k_scan_skip<false, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);

@@ -926,7 +926,9 @@ __device__ unsigned long long g_ss_prof[8];
 // the compaction is a funnel shift in registers -- the slots that leave the tile are one contiguous run (the b, or the
 // whole word (c, b, SEP) when the word was exactly (a b)), so every later slot moves left by the same s in {1, 3}.
 // No LDS staging, no bitmaps, no scatter.
-template <class AggV, bool HIST = false>
+// WEIGHTED (pooled words): the site's word carries a frequency -- the word's index is tile_wbase + the number of SEP slots in
+// front of the site, counted in registers; nothing but the b leaves the tile (words are never dropped in this layout).
+template <class AggV, bool HIST = false, bool WEIGHTED = false>
 __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile, uint32_t len, const TileRegs &r,
                                                  int lane_s, uint32_t mm_s, unsigned long long &wave_sites,
                                                  unsigned long long &wave_freed) {
@@ -942,7 +944,20 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     const int p = j < 8 ? lane_s * 8 + j : 512 + lane_s * 8 + (j - 8); // the site (wave-uniform)
     const uint32_t L = tile_elem_uniform(r, p - 1), R = tile_elem_uniform(r, p + 2);
     const bool left = L < YB_PAD, right = R < YB_PAD;
-    const bool dead = !left && R == YB_SEP; // the word was exactly (a b): it leaves the stream (yb_site_word_dies)
+    const bool dead = !WEIGHTED && !left && R == YB_SEP; // flat layout: the word was exactly (a b): it leaves the stream (yb_site_word_dies)
+    long long w = 1; // the word's frequency
+    if constexpr (WEIGHTED) {
+        // SEP slots in front of position p: whole groups of the lanes before the site's, the low slots of the site's own group,
+        // all of segment A when the site lies in segment B -- one wave sum, then the frequency is on its way while the tile is rewritten
+        const uint32_t sepA = eq_mask8(r.va, YB_SEP), sepB = eq_mask8(r.vb, YB_SEP);
+        const bool inB = p >= 512;
+        const uint32_t mine = inB ? sepB : sepA, below = (1u << (p & 7)) - 1u;
+        uint32_t cnt = lane < lane_s ? __popc(mine) : lane == lane_s ? __popc(mine & below) : 0u;
+        if (inB) cnt += __popc(sepA);
+        cnt = wave_inclusive_sum(cnt);
+        const uint32_t widx = P.tile_wbase[tile] + (uint32_t)__builtin_amdgcn_readlane(cnt, 63);
+        w = (long long)P.wfreq[widx];
+    }
 
     YB_SS_STAMP(1);
     // (order: the stores go out FIRST -- the signature bits and the LDS deltas below run while they are acknowledged; the
@@ -1021,7 +1036,7 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         if constexpr (HIST) { // lane = role: (L,a) -1, (L,c) +1, (b,R) -1, (c,R) +1
             if (on) atomicAdd(&C.hist[lane * HIST_V + (int)(lane < 2 ? L : R)], (lane & 1) ? 1 : -1);
         } else {
-            if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? 1ll : -1ll);
+            if (on) agg_add(C.agg, P.out, st, lane < 2 ? kl : kr, (lane & 1) ? w : -w);
         }
     }
     YB_SS_STAMP(2);
@@ -2673,7 +2688,6 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
     constexpr int NT = NW * 64;                   // threads of the workgroup (NW waves)
     constexpr int KTM = scan_kt_max(NW);
     static_assert(FULL || NW == WPB, "only the sparse form runs with wider workgroups");
-    static_assert(!(INLINE && WEIGHTED), "the single-site shortcut is for the flat layout");
     __shared__ uint32_t s_n, s_hits, s_nrew;
     __shared__ uint2 s_list[NT * KTM];
     __shared__ uint2 s_rew[(REWRITES && !FULL) ? NT * KTM : 1];
@@ -2801,7 +2815,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
                 bool handled = false;
                 if constexpr (INLINE) {
                     if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        single_site_tile<AggV, false, WEIGHTED>(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
                         handled = true;
 #ifdef YB_PROFILE_SCAN // how long until everything this tile stored is acknowledged (what a conservative vmcnt(0) costs)
                         {
@@ -2860,7 +2874,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
                 bool handled = false;
                 if constexpr (INLINE) {
                     if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
+                        single_site_tile<AggV, false, WEIGHTED>(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
                         handled = true;
                     }
                 }
