@@ -375,10 +375,8 @@ int state_push(yabpe_ctx *c) {
 void table_free(PairTable &t) {
     dfree(t.keys);
     dfree(t.cnt);
-    dfree(t.incand);
     t.keys = nullptr;
     t.cnt = nullptr;
-    t.incand = nullptr;
     t.cand_cs = nullptr;
     t.cand_list = nullptr;
     t.cand_T = 0;
@@ -406,7 +404,7 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.rowmax = nullptr;
     t.dense_v = 0;
     t.entries = entries_ctr;
-    t.incand = nullptr;  // the candidate list is attached to the main table only, once it is built (cand_attach / cand_rebuild)
+    // (the candidate list is attached to the main table only, once it is built: cand_attach / cand_rebuild)
     t.cand_cs = nullptr;
     t.cand_list = nullptr;
     t.cand_T = 0;
@@ -482,11 +480,6 @@ int cand_attach(yabpe_ctx *c) {
     t.cand_cs = nullptr;
     t.cand_list = nullptr;
     if (!optv(c, "cand_argmax", 1)) return 0;
-    if (!t.dense) {
-        const uint64_t words = incand_words(t.cap);
-        if (!t.incand) TRY(dmalloc(c, &t.incand, words));
-        HIPCHK(c, hipMemsetAsync(t.incand, 0, words * 4, c->stream));
-    }
     if (!c->sel_ticket) {
         TRY(dmalloc(c, &c->sel_ticket, TICKET_WORDS));
         HIPCHK(c, hipMemsetAsync(c->sel_ticket, 0, TICKET_WORDS * 4, c->stream));
@@ -506,15 +499,13 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->table.cand_cs = nullptr;
     c->table.cand_list = nullptr;
     const bool dense = c->table.dense != nullptr;
-    if (!optv(c, "cand_argmax", 1) || (!dense && !c->table.incand) || !c->cand_state || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
-    const uint64_t words = dense ? 0 : incand_words(c->table.cap);
+    if (!optv(c, "cand_argmax", 1) || !c->cand_state || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
     const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 768));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
     CandState h{};
     for (int attempt = 0; attempt < 12; ++attempt) {
         unsigned long long margin = (unsigned long long)((double)best_count * c->cand_margin);
         if (margin < 1) margin = 1;
-        if (!dense) HIPCHK(c, hipMemsetAsync(c->table.incand, 0, words * 4, c->stream));
         h = CandState{best_count - std::min(margin, best_count - 1), 0u, 0u, 0u, 0u};
         HIPCHK(c, hipMemcpyAsync(c->cand_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         PairTable t = c->table;

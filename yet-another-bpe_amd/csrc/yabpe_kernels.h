@@ -94,7 +94,6 @@ struct PairTable {
     uint32_t max_probe;
     unsigned long long *entries; // where successful inserts are counted
     // candidate argmax (main table only, else NULL): a count that rises to >= cand_T puts its slot on the candidate list
-    uint32_t *incand;            // bitmap: slots already in the candidate list
     CandState *cand_cs;          // list length / overflow flag
     unsigned long long *cand_list; // entries: slot | key << 32
     unsigned long long cand_T;
@@ -104,7 +103,7 @@ struct PairTable {
     DeltaHdr *sink_hdr;
     uint32_t sink_cap;
     // Direct-indexed form (the main table by default): dense != NULL -- one u64 count per POSSIBLE pair of the dense_v tokens
-    // the matrix has rows for, no keys, no probing, no inserts (keys / cnt / cap / incand are unused).  Pair (x, y) belongs
+    // the matrix has rows for, no keys, no probing, no inserts (keys / cnt / cap are unused).  Pair (x, y) belongs
     // to the row of its YOUNGER token o = max(x, y): row o holds the 2 (o + 1) pairs (o, j <= o) and (j < o, o), rows are
     // stored one after the other (row o starts at o (o + 1)).  A merge only ever CREATES adjacencies with the token it has
     // just made, so all the counts that go up in a merge lie in that one new row, and a row never grows after the merge
@@ -120,8 +119,6 @@ YB_HD unsigned long long tri_idx(uint32_t key) {
 }
 YB_HD unsigned long long tri_size(uint32_t v) { return (unsigned long long)v * ((unsigned long long)v + 1ull); } // entries of rows 0 .. v-1
 YB_HD uint32_t tri_key(uint32_t o, uint32_t j) { return j <= o ? ((o << 16) | j) : (((j - o - 1u) << 16) | o); } // entry j of row o
-// words of the `incand` bitmap of a table of `cap` slots
-YB_HD uint32_t incand_words(uint32_t cap) { return (((cap + 31u) >> 5) + 4u) & ~3u; }
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
 __device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
     return (uint32_t)(((unsigned long long)hash32(key) * t.cap) >> 32);
@@ -243,13 +240,15 @@ __device__ __forceinline__ void st_coherent(uint32_t *p, uint32_t v) { __hip_ato
 __device__ __forceinline__ unsigned long long ld_coherent(const unsigned long long *p) { return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p) { return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// The count of slot s rose to `now`: once it reaches the threshold of the candidate argmax the slot joins the list (once).
-// Invariant kept between two rebuilds of the list: every slot whose count is >= cand_T is on it.  Counts only go up
-// through the two functions below, so nothing else has to look at the table.
-__device__ __forceinline__ void cand_note(const PairTable &t, uint32_t s, uint32_t key, unsigned long long now) {
-    if (now < t.cand_T || (long long)now <= 0) return;
-    const uint32_t bit = 1u << (s & 31);
-    if (atomicOr(&t.incand[s >> 5], bit) & bit) return;
+// The count of slot s rose from `old` to `now`: the add that takes it across the threshold of the candidate argmax puts the slot
+// on the list.  Adds to one address are totally ordered, so exactly one adder sees the crossing; a count that falls below the
+// threshold and crosses again is listed twice, which is harmless (the same slot, the same count).  (Until round 2 every adder
+// that saw a count >= T tried to list it and a bitmap kept the list free of repeats: one more dependent atomic in the flush of
+// exactly the workgroups that finish last.)  Invariant kept between two rebuilds of the list: every slot whose count is
+// >= cand_T is on it.  Counts only go up through the two functions below, so nothing else has to look at the table.
+// (Signed comparisons: a count can be transiently negative while the deltas of one merge arrive in any order.)
+__device__ __forceinline__ void cand_note(const PairTable &t, uint32_t s, uint32_t key, unsigned long long old, unsigned long long now) {
+    if ((long long)now < (long long)t.cand_T || (long long)old >= (long long)t.cand_T || (long long)now <= 0) return;
     const uint32_t idx = atomicAdd(&t.cand_cs->n, 1u);
     if (idx < CAND_CAP)
         st_coherent(&t.cand_list[idx], (unsigned long long)s | ((unsigned long long)key << 32));
@@ -266,7 +265,7 @@ __device__ __forceinline__ void gt_bump_dense(const PairTable &t, uint32_t key, 
     unsigned long long *p = &t.dense[tri_idx(key)];
     if (d > 0 && t.cand_list) {
         const unsigned long long old = atomicAdd(p, (unsigned long long)d), now = old + (unsigned long long)d;
-        if (old < t.cand_T && now >= t.cand_T && (long long)now > 0) {
+        if ((long long)old < (long long)t.cand_T && (long long)now >= (long long)t.cand_T && (long long)now > 0) {
             const uint32_t idx = atomicAdd(&t.cand_cs->n, 1u);
             if (idx < CAND_CAP)
                 st_coherent(&t.cand_list[idx], (unsigned long long)key << 32);
@@ -285,7 +284,7 @@ __device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t
     }
     if (d > 0 && t.cand_list) {
         const unsigned long long old = atomicAdd(&t.cnt[s], (unsigned long long)d);
-        cand_note(t, s, key, old + (unsigned long long)d);
+        cand_note(t, s, key, old, old + (unsigned long long)d);
     } else {
         atomicAdd(&t.cnt[s], (unsigned long long)d);
     }
@@ -2555,7 +2554,6 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < P.table.cap; s += gridDim.x * BLOCK) {
         const long long cn = (long long)P.table.cnt[s];
         if (cn <= 0 || (unsigned long long)cn < T) continue;
-        atomicOr(&P.table.incand[s >> 5], 1u << (s & 31));
         const uint32_t idx = atomicAdd(&P.cs->n, 1u);
         if (idx < CAND_CAP) P.table.cand_list[idx] = (unsigned long long)s | ((unsigned long long)P.table.keys[s] << 32); else P.cs->overflow = 1u;
     }
