@@ -1389,6 +1389,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                       // initialise and to flush); the count of the LAST batch's merge bounds this batch's (it never rises)
                       (uint32_t)(optv(c, "agg_small", 1) && c->split_mode && !c->weighted && c->st_host->best_count * 4 < 48ull * std::max<uint32_t>(1u, c->n_cu * 3) ? AGG_N / 4 - 1 : AGG_N - 1)};  // signatures are maintained in the split form only
         if (!c->split_mode) {
+            P.stats_fresh = 1;  // (one apply launch per merge in this form)
             const FuseParams F = fuse_params(apply_grid);
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
@@ -1447,6 +1448,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
                                   scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, chunk, R, fuse_params(full ? scan_grid : 0u)};
                 if (!full) SQ.F.ticket = nullptr;  // (can_fuse() never asks for this form)
+                SQ.A.stats_fresh = full ? 1u : 0u;  // (the other forms rewrite in two launches per merge, both add to the slots)
                 // (a workgroup of 16 waves collects twice the deltas of one of 8: the small aggregator grows with it, or its
                 // probe windows fill and updates go to the table one by one from inside the candidate loop)
                 if (nw >= 16 && SQ.A.agg_mask == (uint32_t)AGG_N / 4 - 1) SQ.A.agg_mask = (uint32_t)(AGG_N / std::max<int64_t>(1, optv(c, "agg_wide_div", 2))) - 1;

@@ -747,6 +747,8 @@ struct ApplyParams {
     uint32_t sig_stride;
     uint32_t cas_first;            // flush: claim the home slot of a pair that contains the new token without looking first
     uint32_t agg_mask;             // k_scan_skip: LDS aggregator entries in use - 1 (a power of two - 1, <= AGG_N - 1)
+    uint32_t stats_fresh;          // 1: this launch is the only one of its merge that writes blk_stats (the selection cleared them):
+                                   // a workgroup stores its counters without reading the slot first (a dependent load in front of every flush)
 };
 
 // lane i <- lane i+1's value, lane 63 <- fill (one DPP move, no LDS crossbar)
@@ -1255,8 +1257,13 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
     }
     __syncthreads();
     if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { // one slot per workgroup, no atomics; the selection sums and clears them
-        st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]); // (it may run in this very launch)
-        st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
+        if (P.stats_fresh) {
+            st_coherent(&P.blk_stats[2 * blockIdx.x], s_cnt[0]); // (the selection may run in this very launch)
+            st_coherent(&P.blk_stats[2 * blockIdx.x + 1], s_cnt[1]);
+        } else {
+            st_coherent(&P.blk_stats[2 * blockIdx.x], P.blk_stats[2 * blockIdx.x] + s_cnt[0]);
+            st_coherent(&P.blk_stats[2 * blockIdx.x + 1], P.blk_stats[2 * blockIdx.x + 1] + s_cnt[1]);
+        }
     }
     if (hist) // (the direct-indexed store of merge (ha, hb) -> hc)
         hist_flush(Hist{hist}, ha, hb, hc, P.out, st, newtok);
