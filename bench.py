@@ -262,33 +262,6 @@ def main() -> None:
             tiles_read = st["scan_skip_tiles_read"] / max(1, st["scan_skip_launches"])
             out["latency"]["event_timed"] = {"launches": n_l, "avg_launch_us": round(1e3 * st["scan_ms_sampled"] / max(1, n_l), 2),
                                              "avg_fraction_of_tiles_read": round(tiles_read / max(1, st["n_tiles"]), 4)}
-    aux_merges = min(args.merges, args.roofline_merges)
-    if aux_merges > 0 and "roofline" in out:
-        # the scan alone (k_scan: the streaming match without rewrite), an auxiliary pass that is NOT on the timed path:
-        # skip index off, split form, first `aux_merges` merges of the same resident corpus
-        def aux_job():
-            if runner is not None:
-                return runner.run(aux_merges, 1, event_sample=4, options={"skip_index": 0, "split": 1})
-            with _native.Context(local_rank) as ctx:
-                ctx.set_option("event_sample", 4)
-                ctx.set_option("skip_index", 0)
-                ctx.set_option("split", 1)
-                ctx.set_vocab(base)
-                ctx.load_words_ptr(pb, po, n_words)
-                ctx.train(aux_merges, 1)
-                return {"stats": ctx.stats()}
-
-        sa = aux_job()["stats"]
-        if sa["scan_launches_sampled"]:
-            n_l = sa["scan_launches_sampled"]
-            secs = sa["scan_ms_sampled"] / 1000.0
-            algo, actual = sa["scan_algo_bytes_sampled"], sa["scan_actual_bytes_sampled"]
-            out["roofline"]["scan_only"] = {
-                "kernel": "k_scan", "frac": round(algo / secs / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(algo / secs / 1e9, 1),
-                "actual_stream_GBps": round(actual / secs / 1e9, 1), "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / n_l, 2),
-                "note": f"auxiliary pass, not on the timed path: the streaming match alone (no rewrite, no table update, no selection), skip index off, "
-                        f"first {aux_merges} merges, every 4th launch timed -- what the read side of the tiling can do",
-            }
     if rank == 0 and not args.no_dedup_line and world == 1:
         t1 = time.perf_counter()
         rd = one_job(True, 0)

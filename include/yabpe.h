@@ -132,6 +132,8 @@ typedef struct yabpe_stats_t {
     /* multi-GPU: all-gathers of [header | records] buffers (one per merge), bytes every rank receives per exchange, record
        capacity per rank, times the buffers had to grow (a merge produced more records than fit: global recount) */
     uint64_t exchanges, exchange_bytes, exchange_cap_records, exchange_growths, exchange_max_records;
+    /* launches of the sparse phase: one launch applies a BATCH of merges (sparse_merges / sparse_launches = mean batch) */
+    uint64_t sparse_launches;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

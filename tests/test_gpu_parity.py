@@ -157,13 +157,14 @@ def test_many_tiles_retile_and_table_growth():
                                               "retile_min_tiles": 16, "apply_blocks": 3})
     assert (v2, m2) == (exp_vocab, exp_merges)
     assert s2["retiles"] >= 1
-    # the plain streaming scan (skip index off) and the always-split / never-split forms give the same result
-    for opts in ({"skip_index": 0}, {"split": 1}, {"split": 0}, {"sig_rebuild_every": 3, "check_interval": 2}, {"fuse_skip": 1}, {"inline_single": 0}, {"rank_rides": 0}, {"dense_worklist": 1}, {"dense_worklist": 0}, {"cand_argmax": 0}, {"cand_min_count": 1, "check_interval": 3},
-                 {"fuse_select": 0}, {"cand_rebuild_every": 1}, {"cand_rebuild_every": 100000, "check_interval": 8}, {"full_skip": 0}, {"dense_worklist": 1, "inline_single": 0}, {"scan_skip_blocks": 2, "full_skip_blocks": 2}, {"dense_worklist": 1, "full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
-                 {"apply_skip_blocks": 3, "retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "skip_index": 0, "retile_pct": 95, "retile_min_tiles": 16},
-                 {"fused": 0}, {"fused": 1, "check_interval": 3}, {"cand_target": 64, "check_interval": 4}, {"cas_first": 1}, {"table_load_pct": 70, "table_grow_x": 2},
-                 {"dense_table": 1}, {"dense_table": 1, "check_interval": 3, "cand_target": 64}, {"dense_table": 1, "fused": 0}, {"dense_table": 1, "cand_argmax": 0},
-                 {"full_wpb": 4}, {"full_wpb": 8}, {"full_wpb": 16}, {"full_wpb": 16, "full_skip_blocks": 3}, {"full_wpb": 8, "dense_worklist": 1, "check_interval": 5},
+    # the always-sparse / never-sparse forms, every batch limit, unfused selection, ... give the same result
+    for opts in ({"split": 1}, {"split": 0}, {"sig_rebuild_every": 3, "check_interval": 2}, {"rank_rides": 0}, {"cand_argmax": 0}, {"cand_min_count": 1, "check_interval": 3},
+                 {"batch_max": 1}, {"batch_max": 2}, {"batch_max": 3, "check_interval": 5}, {"batch_max": 8, "check_interval": 1}, {"batch_max": 8, "split": 1, "check_interval": 3},
+                 {"batch_max": 8, "cand_min_count": 1, "split": 1}, {"batch_max": 8, "cand_target": 64, "check_interval": 4}, {"batch_max": 8, "full_wpb": 16}, {"batch_max": 8, "full_wpb": 4, "agg_small": 0},
+                 {"fuse_select": 0}, {"cand_rebuild_every": 1}, {"cand_rebuild_every": 100000, "check_interval": 8}, {"full_skip_blocks": 2}, {"full_skip_blocks": 1}, {"sig_rebuild_pct": 0, "check_interval": 5},
+                 {"retile_pct": 95, "retile_min_tiles": 16}, {"split": 1, "retile_pct": 95, "retile_min_tiles": 16},
+                 {"fused": 0}, {"fused": 0, "split": 1}, {"fused": 1, "check_interval": 3}, {"cand_target": 64, "check_interval": 4}, {"table_load_pct": 70, "table_grow_x": 2},
+                 {"full_wpb": 4}, {"full_wpb": 8}, {"full_wpb": 16}, {"full_wpb": 16, "full_skip_blocks": 3}, {"full_wpb": 8, "check_interval": 5},
                  {"hist": 0}, {"hist": 0, "split": 0}, {"split": 0}, {"split": 0, "apply_blocks": 5, "check_interval": 3}):
         v3, m3 = _native.train_words(flat, off, None, base, 600, 1, options={"verify": 1, **opts})
         assert (v3, m3) == (exp_vocab, exp_merges), opts
@@ -194,12 +195,12 @@ def test_streaming_form_across_the_direct_store_limit():
 
 
 def test_weighted_layout_split_forms():
-    """Pooled words + counts through every form of the split apply (lists, dense list, rewrite inside the scan)."""
+    """Pooled words + counts through the sparse form (batches of merges, wide and narrow workgroups, unfused) and the streaming one."""
     words = helpers.corpus_en_words()
     uw, fq = helpers.pooled(words)
     exp = oracle.merge_loop(words, 257 + 1200, 1, SP)
-    for opts in ({"split": 1}, {"split": 1, "dense_worklist": 1}, {"split": 1, "dense_worklist": 1, "full_skip": 0},
-                 {"split": 1, "dense_worklist": 0}, {"split": 1, "skip_index": 0}, {"dense_table": 1}, {"dense_table": 1, "split": 1, "check_interval": 5}):
+    for opts in ({"split": 1}, {"split": 1, "batch_max": 1}, {"split": 1, "batch_max": 2, "check_interval": 5}, {"split": 1, "full_wpb": 4},
+                 {"split": 1, "fused": 0}, {"split": 0}, {"cand_min_count": 1, "split": 1, "check_interval": 3}):
         assert gpu_train(uw, fq, 257 + 1200, 1, SP, options={"verify": 1, **opts}) == exp, opts
 
 

@@ -36,18 +36,17 @@ def resources():
 
 
 def test_sparse_launch_keeps_four_waves_per_simd(resources):
-    # k_scan_skip<INLINE, FULL=true, WEIGHTED, NW>: the production forms are NW = 8 and 16 (flat <1,1,0,*>, pooled <0,1,1,*>)
+    # k_scan_skip<WEIGHTED, NW>: the production forms are NW = 8 and 16 (flat <0,*>, pooled <1,*>)
     seen = 0
     for name, r in resources.items():
-        m = re.match(r"_ZN2yb11k_scan_skipILb([01])ELb1ELb([01])ELi(8|16)E", name)
+        m = re.match(r"_ZN2yb11k_scan_skipILb([01])ELi(8|16)E", name)
         if not m:
             continue
         seen += 1
         assert r["VGPRs"] <= 128 and r["Occupancy"] >= 4, (name, r)
-        nw = int(m.group(3))
+        nw = int(m.group(2))
         assert r["LDS"] * (16 // nw) <= 160 * 1024, (name, r)  # 16 waves per CU resident
-        if (m.group(1), m.group(2)) in (("1", "0"), ("0", "1")):  # the two production layouts: no scratch
-            assert r["ScratchSize"] == 0, (name, r)
+        assert r["ScratchSize"] == 0, (name, r)
     assert seen >= 4
 
 

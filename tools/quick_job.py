@@ -35,7 +35,8 @@ with _native.Context() as g:
             it, us, scan = ctx.event_log()
             sites, live = ctx.iter_log()
         print(f"run {run}: {len(left)} merges, wall {wall*1e3:.1f} ms, train_ms {st['train_ms']:.1f}, {len(left)/wall:.0f} merges/s | fused {st['fused_launches']} "
-              f"cand_rebuilds {st['cand_rebuilds']} rescans {st['cand_rescans']} retiles {st['retiles']} table_rebuilds {st['table_rebuilds']} cap {st['table_capacity']} entries {st['table_entries']}", flush=True)
+              f"cand_rebuilds {st['cand_rebuilds']} rescans {st['cand_rescans']} retiles {st['retiles']} table_rebuilds {st['table_rebuilds']} cap {st['table_capacity']} entries {st['table_entries']} | sparse: {st['sparse_merges']} merges in {st['sparse_launches']} launches "
+              f"(mean batch {st['sparse_merges'] / max(1, st['sparse_launches']):.2f}), {st['sparse_ms']:.1f} ms = {1e3 * st['sparse_ms'] / max(1, st['sparse_merges']):.2f} us per merge; second half {1e3 * st['tail_ms'] / max(1, st['tail_merges']):.2f} us per merge", flush=True)
 if len(it):
     edges = [0, 50, 150, 300, 1000, 3000, 8000, 12000, 20000, 32000, 50000]
     it = np.asarray(it); us = np.asarray(us)

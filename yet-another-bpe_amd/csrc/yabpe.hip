@@ -78,7 +78,7 @@ Rccl *rccl() {
 }
 
 constexpr uint32_t MAX_APPLY_BLOCKS = 8192;
-constexpr uint32_t DENSE_CAP = 4096;  // dense worklist entries (sparse merges)
+constexpr uint32_t MAX_LISTS = 2048;  // the sparse launch's scan workgroups at most (blk_read slots)
 thread_local std::string g_create_error;
 
 struct EventPair {
@@ -146,12 +146,9 @@ struct yabpe_ctx {
                                               // [7] comm_max [8] exchange record count [9] local count-table entries
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
     uint32_t blk_used = 0;                    // largest grid that wrote blk_stats since they were last folded
-    // split apply: worklist of tiles that contain the pair
-    uint2 *work = nullptr;
-    uint32_t *work_cnt = nullptr;
-    uint2 *work_dense = nullptr;  // sparse merges: one list for all workgroups
-    uint64_t work_cap = 0;
-    bool split_mode = false;
+    bool split_mode = false;         // the sparse form (skip index + batches of merges per launch) instead of the streaming one
+    uint32_t kmax_now = 1;           // DevState::kmax as last written
+    uint32_t rec_n_live = 0;         // record entries to keep when the record arrays grow
     std::vector<float> ev_scan_us;
     // skip index
     unsigned long long *sig = nullptr;
@@ -162,7 +159,6 @@ struct yabpe_ctx {
     uint32_t sig_built_at = 0;
     uint64_t sig_tokens_at_build = 0;  // T when the signatures were last built (stale bits grow with the sites merged since)
     uint64_t sig_builds = 0;
-    bool dense_mode = false;  // few multi-site tiles expected per merge: dense worklist + small k_slow grid
     // candidate argmax
     CandState *cand_state = nullptr;
     uint32_t cand_built_at = 0;      // merge index (of this yabpe_train call) at which cand[] was last rebuilt
@@ -172,11 +168,6 @@ struct yabpe_ctx {
     bool use_cand = false;
     uint64_t cand_rebuilds = 0, cand_rescans = 0;
     double cand_margin = 0.2;        // T = best count x (1 - margin); adapted so that the list stays short
-    // direct-indexed count matrix (c->table.dense): rows the host lists for a scan
-    uint32_t *scan_rows = nullptr;   // device, YB_MAX_TOKENS entries
-    uint32_t n_scan_rows = 0;
-    uint64_t matrix_growths = 0;
-    uint64_t local_count_cap = 0;    // multi-GPU recounts: slots of the per-rank hash table the local count goes through
     uint32_t cand_n_at_build = 0;
     // fused per-merge launch: the apply kernel of merge i ends with the selection of merge i + 1
     bool pending = false;            // a merge has been selected (recorded) and not applied yet
@@ -383,11 +374,6 @@ void table_free(PairTable &t) {
     t.sink_rec = nullptr;
     t.sink_hdr = nullptr;
     t.sink_cap = 0;
-    dfree(t.dense);
-    dfree(t.rowmax);
-    t.dense = nullptr;
-    t.rowmax = nullptr;
-    t.dense_v = 0;
 }
 
 int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *entries_ctr) {
@@ -400,9 +386,6 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.sink_rec = nullptr;
     t.sink_hdr = nullptr;
     t.sink_cap = 0;
-    t.dense = nullptr;
-    t.rowmax = nullptr;
-    t.dense_v = 0;
     t.entries = entries_ctr;
     // (the candidate list is attached to the main table only, once it is built: cand_attach / cand_rebuild)
     t.cand_cs = nullptr;
@@ -410,66 +393,6 @@ int table_alloc(yabpe_ctx *c, PairTable &t, uint64_t cap, unsigned long long *en
     t.cand_T = 0;
     HIPCHK(c, hipMemsetAsync(t.keys, 0xFF, cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(unsigned long long), c->stream));
-    return 0;
-}
-
-// ---------------------------------------------------------------- direct-indexed count matrix (PairTable::dense)
-bool want_dense(yabpe_ctx *c) { return optv(c, "dense_table", 0) != 0; }  // (measured equal to the hash table at 12-30 % load: kept as an option)
-
-// a zeroed matrix with rows for `v` tokens (the rest of PairTable stays empty: no keys, no probing)
-int dense_alloc(yabpe_ctx *c, PairTable &t, uint32_t v) {
-    t = PairTable{};
-    TRY(dmalloc(c, &t.dense, tri_size(v)));
-    TRY(dmalloc(c, &t.rowmax, v));
-    t.dense_v = v;
-    t.entries = &c->st->table_entries;
-    HIPCHK(c, hipMemsetAsync(t.dense, 0, tri_size(v) * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(t.rowmax, 0, (size_t)v * 8, c->stream));
-    return 0;
-}
-
-// rows for at least `need_v` tokens: a bigger matrix takes over the old rows (rows are stored one after the other, so the
-// old matrix is a prefix of the new one)
-int dense_ensure_rows(yabpe_ctx *c, uint32_t need_v) {
-    PairTable &t = c->table;
-    need_v = std::min<uint32_t>(need_v, YB_MAX_TOKENS);
-    if (!t.dense || t.dense_v >= need_v) return 0;
-    const uint32_t new_v = std::min<uint32_t>(YB_MAX_TOKENS, std::max<uint32_t>(need_v, t.dense_v + t.dense_v / 2 + 1024));
-    unsigned long long *nd = nullptr, *nr = nullptr;
-    TRY(dmalloc(c, &nd, tri_size(new_v)));
-    TRY(dmalloc(c, &nr, new_v));
-    HIPCHK(c, hipMemcpyAsync(nd, t.dense, tri_size(t.dense_v) * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(nd + tri_size(t.dense_v), 0, (tri_size(new_v) - tri_size(t.dense_v)) * 8, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nr, t.rowmax, (size_t)t.dense_v * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(nr + t.dense_v, 0, (size_t)(new_v - t.dense_v) * 8, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dfree(t.dense);
-    dfree(t.rowmax);
-    t.dense = nd;
-    t.rowmax = nr;
-    t.dense_v = new_v;
-    c->table_cap = tri_size(new_v);
-    c->matrix_growths++;
-    return 0;
-}
-
-// The rows a scan has to read: tokens whose bound rowmax is >= `bound`, plus `extra` rows past the tokens that exist now
-// (tokens the launches of the coming batch may create: their rows are zero until then).  One small copy each way.
-int dense_list_rows(yabpe_ctx *c, uint32_t n_tokens, unsigned long long bound, uint32_t extra) {
-    const PairTable &t = c->table;
-    n_tokens = std::min(n_tokens, t.dense_v);
-    std::vector<unsigned long long> rm(n_tokens);
-    if (n_tokens) HIPCHK(c, hipMemcpyAsync(rm.data(), t.rowmax, (size_t)n_tokens * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> rows;
-    rows.reserve(n_tokens + extra);
-    for (uint32_t o = 0; o < n_tokens; ++o)
-        if (rm[o] >= bound) rows.push_back(o);
-    for (uint32_t o = n_tokens; o < std::min<uint32_t>(t.dense_v, n_tokens + extra); ++o) rows.push_back(o);
-    if (!c->scan_rows) TRY(dmalloc(c, &c->scan_rows, YB_MAX_TOKENS));
-    c->n_scan_rows = (uint32_t)rows.size();
-    if (!rows.empty()) HIPCHK(c, hipMemcpyAsync(c->scan_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -498,7 +421,6 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
     c->use_cand = false;
     c->table.cand_cs = nullptr;
     c->table.cand_list = nullptr;
-    const bool dense = c->table.dense != nullptr;
     if (!optv(c, "cand_argmax", 1) || !c->cand_state || best_count < (unsigned long long)optv(c, "cand_min_count", 16)) return 0;
     const uint32_t target = (uint32_t)std::max<int64_t>(64, optv(c, "cand_target", 768));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
@@ -512,13 +434,7 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
         t.cand_list = c->cand;
         t.cand_cs = c->cand_state;
         t.cand_T = h.T;
-        if (dense) {  // only the rows that can hold a count >= T (their bounds are refreshed on the way)
-            TRY(dense_list_rows(c, c->st_host->n_tokens, h.T, 0));
-            if (c->n_scan_rows) {
-                DenseScanParams D{t, c->scan_rows, c->n_scan_rows, c->tt.rec, nullptr, c->st, (c->pending && c->st_host->c_is_new) ? c->st_host->c : EMPTY};
-                hipLaunchKernelGGL(k_dense_scan<true>, dim3(std::min<uint32_t>(c->n_scan_rows, 2048)), dim3(BLOCK), 0, c->stream, D);
-            }
-        } else {
+        {
             CandParams P{t, c->tt.rec, c->partials, c->st, c->cand_state, nullptr, SelectParams{}};
             hipLaunchKernelGGL(k_cand_rebuild, dim3(grid), dim3(BLOCK), 0, c->stream, P);
         }
@@ -698,7 +614,7 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
     if (!c->multi) return launch_count_local(c, t);
     // generic multi-GPU count: local table -> records -> all-gather -> sum into t
     PairTable lt{};
-    const uint64_t lcap = t.dense ? std::max<uint64_t>(c->local_count_cap, 1ull << 20) : (uint64_t)t.cap;
+    const uint64_t lcap = (uint64_t)t.cap;
     HIPCHK(c, hipMemsetAsync(&c->scratch64[9], 0, 8, c->stream));
     TRY(table_alloc(c, lt, lcap, &c->scratch64[9]));
     TRY(launch_count_local(c, lt));
@@ -709,37 +625,6 @@ int launch_count(yabpe_ctx *c, PairTable t, bool all_bytes = false) {
 
 // (Re)build the pair table from the token stream with at least `min_cap` slots; grows until the load is <= 1/2.
 int table_rebuild(yabpe_ctx *c, uint64_t min_cap, bool all_bytes = false) {
-    if (want_dense(c)) {
-        // direct-indexed counts: zero the rows of the tokens that exist and count again (multi-GPU: through local tables and
-        // one exchange; a local table that is too small is the only thing that can fail here, and all ranks retry together)
-        TRY(state_pull(c));
-        const uint32_t n_tok = c->st_host->n_tokens;
-        if (!c->table.dense || c->table.dense_v < n_tok) {
-            table_free(c->table);
-            TRY(dense_alloc(c, c->table, std::min<uint32_t>(YB_MAX_TOKENS, n_tok + 1024)));
-        }
-        c->table_cap = tri_size(c->table.dense_v);
-        for (int attempt = 0; attempt < 8; ++attempt) {
-            c->table.cand_cs = nullptr;
-            c->table.cand_list = nullptr;
-            HIPCHK(c, hipMemsetAsync(c->table.dense, 0, tri_size(n_tok) * 8, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->table.rowmax, 0xFF, (size_t)n_tok * 8, c->stream));  // (unknown until a scan refreshes them)
-            HIPCHK(c, hipMemsetAsync(&c->st->table_entries, 0, sizeof(unsigned long long), c->stream));
-            HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, sizeof(uint32_t), c->stream));
-            c->local_count_cap = std::max<uint64_t>(c->local_count_cap, 1ull << 20);
-            TRY(launch_count(c, c->table, all_bytes));
-            TRY(state_pull(c));
-            unsigned long long bad = c->st_host->halt_req != 0 ? 1 : 0, any_bad = 0;
-            TRY(comm_max(c, bad, &any_bad));
-            if (!any_bad) {
-                c->stats.table_rebuilds++;
-                TRY(cand_attach(c));
-                return 0;
-            }
-            c->local_count_cap *= 4;
-        }
-        return fail(c, YABPE_E_CAPACITY, "local count table does not fit");
-    }
     uint64_t cap = std::max<uint64_t>(min_cap, 1ull << optv(c, "table_min_log2", 16));
     bool shrunk = false;
     for (int attempt = 0; attempt < 16; ++attempt) {
@@ -990,14 +875,10 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->st);
     dfree(c->scratch64);
     dfree(c->blk_stats);
-    dfree(c->work);
-    dfree(c->work_cnt);
-    dfree(c->work_dense);
     dfree(c->blk_read);
     dfree(c->cand_state);
     dfree(c->sel_ticket);
     dfree(c->cand);
-    dfree(c->scan_rows);
     dfree(c->xsend);
     dfree(c->xrecv);
     dfree(c->xsmall);
@@ -1064,6 +945,8 @@ int yabpe_set_vocab(yabpe_ctx *c, const uint8_t *tok_bytes, const uint32_t *tok_
     for (uint32_t i = 0; i < n_tokens; ++i) {
         rec[i].len = len[i];
         rec[i].hash = yb_hash_bytes(pool.data() + off[i], len[i]);
+        rec[i].pre8 = yb_pre8(pool.data() + off[i], len[i]);
+        rec[i].pad = 0;
         uint32_t s = yb_vset_home(rec[i].hash, len[i]) & c->tt.vset_mask;
         while (vset[s] != VSET_EMPTY) s = (s + 1) & c->tt.vset_mask;
         vset[s] = yb_vset_entry(i, rec[i].hash);
@@ -1265,6 +1148,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.dense_actual_bytes_sampled = 0;
     c->stats.sparse_ms = 0;
     c->stats.sparse_merges = 0;
+    c->stats.sparse_launches = 0;
     c->stats.tail_ms = 0;
     c->stats.tail_merges = 0;
     c->stats.scan_ms_sampled = 0;
@@ -1287,36 +1171,17 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
 }
 
 // ---------------------------------------------------------------------------------------------- train
-static int ensure_worklist(yabpe_ctx *c, uint32_t scan_grid, uint32_t seg) {
-    const uint64_t need = (uint64_t)scan_grid * seg;
-    if (need > c->work_cap || !c->work) {
-        dfree(c->work);
-        c->work = nullptr;
-        TRY(dmalloc(c, &c->work, need));
-        c->work_cap = need;
-    }
-    if (!c->work_cnt) {
-        TRY(dmalloc(c, &c->work_cnt, MAX_LISTS));
-        HIPCHK(c, hipMemsetAsync(c->work_cnt, 0, MAX_LISTS * 4, c->stream));
-        TRY(dmalloc(c, &c->blk_read, MAX_LISTS));
-        HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
-        TRY(dmalloc(c, &c->work_dense, DENSE_CAP));
-    }
-    return 0;
-}
-
 static SelectParams select_params(yabpe_ctx *c, uint32_t rec_base, uint32_t n_part, uint32_t n_blk) {
     return SelectParams{c->partials, n_part, c->tt, c->st, c->rec_left, c->rec_right, c->rec_merged,
                         c->rec_count, c->rec_sites, c->rec_live, rec_base, c->table,
                         c->multi ? reinterpret_cast<DeltaHdr *>(c->xsend) : nullptr, c->blk_stats, std::max(n_blk, 1u),
-                        c->use_cand ? c->cand_state : nullptr};
+                        c->use_cand ? c->cand_state : nullptr, (!c->weighted && !c->multi) ? 1u : 0u};
 }
 
 // The selection as launches of its own (trainer.py:241-251, 296-300): exact argmax over the candidate list, or over the
-// whole table when there is no list, then stop rules and merged-token creation.
+// whole table when there is no list, then stop rules and merged-token creation.  Selects ONE merge.
 static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
-    const uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64)
-                            : c->table.dense ? std::max(1u, std::min<uint32_t>(c->n_scan_rows, c->n_partials)) : c->n_partials;
+    const uint32_t n_part = c->use_cand ? std::min<uint32_t>(c->n_partials_cap, 64) : c->n_partials;
     const SelectParams S = select_params(c, rec_base, n_part, c->blk_used);
     c->blk_used = 0;  // the selection folds and clears them; what follows counts the next merge's grids
     bool selected = false;
@@ -1325,9 +1190,6 @@ static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
         CandParams CP{c->table, c->tt.rec, c->partials, c->st, c->cand_state, fuse ? c->sel_ticket : nullptr, S};
         hipLaunchKernelGGL(k_argmax_cand, dim3(n_part), dim3(BLOCK), 0, c->stream, CP);
         selected = fuse;
-    } else if (c->table.dense) {  // the rows the batch prologue listed (dense_list_rows): every row that may hold a pair
-        DenseScanParams D{c->table, c->scan_rows, c->n_scan_rows, c->tt.rec, c->partials, c->st, EMPTY};
-        hipLaunchKernelGGL(k_dense_scan<false>, dim3(n_part), dim3(BLOCK), 0, c->stream, D);
     } else {
         ArgmaxParams A{c->table, c->tt.rec, c->partials, c->st};
         hipLaunchKernelGGL(k_argmax_partial, dim3(c->n_partials), dim3(BLOCK), 0, c->stream, A);
@@ -1337,24 +1199,23 @@ static int launch_select(yabpe_ctx *c, uint32_t rec_base) {
     return 0;
 }
 
-// Can the apply launch of the merge that is selected now end with the selection of the next one?
+// Can the apply launch of the merges that are selected now end with the selection of the next ones?
 static bool can_fuse(yabpe_ctx *c) {
     if (!c->use_cand || !optv(c, "fused", 1)) return false;
     if (c->multi) return true;        // the selection rides on the launch that applies the exchanged records (k_delta_apply)
     if (!c->n_tiles) return false;
     if (!c->split_mode) return true;  // k_apply
-    return c->sig && c->sig_valid && !optv(c, "fuse_skip", 0) && c->dense_mode && optv(c, "full_skip", 1);  // k_scan_skip, FULL form
+    return c->sig && c->sig_valid;    // k_scan_skip
 }
 
-// Applies the merge in DevState to the token stream and the pair table (trainer.py:254-294).  fuse: the launch that
-// finishes the apply also selects the next merge (its last workgroup; see fused_select_tail) -- one launch per merge.
+// Applies the selected merges (DevState::batch) to the token stream and the pair table (trainer.py:254-294).  fuse: the
+// launch that finishes the apply also selects the next merges (its last workgroup; see fused_select_tail) -- one launch per batch.
 static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, uint32_t apply_grid, EventPair *ev, bool fuse) {
     RankParams R{c->tt, c->st};
-    const uint32_t rank_blocks = cdiv64(tokens_upper, BLOCK);
-    // lexrank maintenance rides on the k_scan_skip launch when that form is used (one dependent launch fewer)
-    // ... and on the fused k_apply launch
-    const bool rank_rides = c->n_tiles && (fuse || optv(c, "rank_rides", 1)) &&
-                            (c->split_mode ? (c->sig && c->sig_valid && !optv(c, "fuse_skip", 0)) : true);
+    const uint32_t rank_blocks = cdiv64(std::min<uint32_t>(tokens_upper, YB_MAX_TOKENS), BLOCK);
+    // lexrank maintenance rides on the apply launch (extra workgroups) whenever there is one over the tiles
+    const bool sparse = c->split_mode && c->sig && c->sig_valid;
+    const bool rank_rides = c->n_tiles && (fuse || optv(c, "rank_rides", 1)) && (c->split_mode ? sparse : true);
     if (!rank_rides) hipLaunchKernelGGL(k_rank_update, dim3(rank_blocks), dim3(BLOCK), 0, c->stream, R);
     // where the apply pass puts its pair-count updates: the pair table, or (multi-GPU) this rank's send buffer as records
     PairTable out_table = c->table;
@@ -1384,12 +1245,9 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     };
     if (c->n_tiles) {
         ApplyParams P{c->tiles, c->tile_len, c->tile_wbase, c->wfreq, c->n_tiles, out_table, c->st, c->blk_stats,
-                      c->split_mode ? c->sig : nullptr, c->sig_stride, (uint32_t)optv(c, "cas_first", 0),
-                      // a sparse merge leaves a workgroup a few dozen deltas: a quarter of the aggregator is plenty (less to
-                      // initialise and to flush); the count of the LAST batch's merge bounds this batch's (it never rises)
-                      (uint32_t)(optv(c, "agg_small", 1) && c->split_mode && !c->weighted && c->st_host->best_count * 4 < 48ull * std::max<uint32_t>(1u, c->n_cu * 3) ? AGG_N / 4 - 1 : AGG_N - 1)};  // signatures are maintained in the split form only
+                      c->split_mode ? c->sig : nullptr, c->sig_stride, (uint32_t)AGG_N - 1u, 1u};  // signatures are maintained in the sparse form only
         if (!c->split_mode) {
-            P.stats_fresh = 1;  // (one apply launch per merge in this form)
+            // streaming form: one merge per launch, one coalesced pass over the live stream
             const FuseParams F = fuse_params(apply_grid);
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
@@ -1400,104 +1258,51 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
-            // pass 1: lean streaming scan (the roofline kernel); pass 2: balanced rewrite of the tiles it listed
-            const uint32_t want = (c->n_tiles + WPB - 1) / WPB;
-            uint32_t scan_grid = 0, seg = 0;
-            bool skip_slow = false;
-            const bool use_sig = c->sig && c->sig_valid;
-            if (use_sig && optv(c, "fuse_skip", 0)) {
-                // signatures + rewrite in one launch, dynamically scheduled
-                const uint32_t n_chunks = (c->n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-                const uint32_t grid = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)optv(c, "apply_skip_blocks", (int64_t)c->n_cu * 6)));
-                c->blk_used = std::max(c->blk_used, grid);
-                TRY(ensure_worklist(c, 1, 1));
-                ApplySkipParams AS{P, n_chunks, c->blk_read};
-                if (c->weighted)
-                    hipLaunchKernelGGL(k_apply_skip<true>, dim3(grid), dim3(BLOCK), 0, c->stream, AS);
-                else
-                    hipLaunchKernelGGL(k_apply_skip<false>, dim3(grid), dim3(BLOCK), 0, c->stream, AS);
-                c->scan_skip_launches++;
-                if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
-            } else {
-            if (use_sig) {
-                // a grid that is resident all at once (no second round of workgroups behind the first): each thread tests
-                // kt tiles' signatures, a workgroup owns SCAN_CHUNK * kt consecutive tiles at a time
-                // sparse merges: the scan also rewrites the few tiles with several sites itself -- no k_slow launch
-                const bool full = c->dense_mode && optv(c, "full_skip", 1);
-                // ... and runs with wide workgroups (full_wpb waves, 16 waves per CU either way): a merge late in a job has its
-                // sites in a few word types, so every workgroup with a site adds to the SAME few table counts -- same-address
-                // atomics are served one after the other, and the queue is as long as there are workgroups; a wider
-                // workgroup also evens out how many matched tiles a wave has to rewrite.
-                // (0 = by the merge: 16 waves once a merge has so few sites that the queue on the hot counts is what is
-                // left -- and the whole stream fits one round of such workgroups -- else 8)
-                int64_t wpb_opt = optv(c, "full_wpb", 0);
-                if (wpb_opt <= 0)
-                    wpb_opt = (c->st_host->best_count <= (unsigned long long)optv(c, "wide_sites_per_cu", 20) * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
-                const uint32_t nw = !full ? (uint32_t)WPB : (wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB);
-                const uint32_t nt = nw * 64u;
-                const uint32_t target = full ? (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)))
-                                             : (uint32_t)std::max<int64_t>(1, optv(c, "scan_skip_blocks", (int64_t)c->n_cu * 4));
-                // tiles per workgroup: what fills `target` workgroups, in whole waves of signature tests, at most kt_max per thread
-                const uint32_t ktm = (uint32_t)scan_kt_max((int)nw);
-                const uint32_t chunk = std::min<uint32_t>(nt * ktm, std::max<uint32_t>(64u, (uint32_t)(((uint64_t)(c->n_tiles + target - 1) / target + 63u) / 64u * 64u)));
-                const uint32_t kt = (chunk + nt - 1) / nt;
-                const uint32_t n_chunks = (c->n_tiles + chunk - 1) / chunk;
-                scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n_chunks, target), MAX_LISTS));
-                seg = chunk * ((n_chunks + scan_grid - 1) / scan_grid);
-                TRY(ensure_worklist(c, scan_grid, seg));
-                ScanSkipParams SQ{ScanParams{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg}, P, c->blk_read,
-                                  scan_grid, (c->dense_mode && !full) ? c->work_dense : nullptr, DENSE_CAP, kt, chunk, R, fuse_params(full ? scan_grid : 0u)};
-                if (!full) SQ.F.ticket = nullptr;  // (can_fuse() never asks for this form)
-                SQ.A.stats_fresh = full ? 1u : 0u;  // (the other forms rewrite in two launches per merge, both add to the slots)
-                // (a workgroup of 16 waves collects twice the deltas of one of 8: the small aggregator grows with it, or its
-                // probe windows fill and updates go to the table one by one from inside the candidate loop)
-                if (nw >= 16 && SQ.A.agg_mask == (uint32_t)AGG_N / 4 - 1) SQ.A.agg_mask = (uint32_t)(AGG_N / std::max<int64_t>(1, optv(c, "agg_wide_div", 2))) - 1;
-                c->blk_used = std::max(c->blk_used, scan_grid);
-                const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
-                const bool inl = optv(c, "inline_single", 1);  // (non-FULL forms: flat layout only, below)
-                if (full) {
-#define YB_LAUNCH_FULL(NW_)                                                                                                   \
-    do {                                                                                                                      \
-        if (c->weighted && inl)                                                                                               \
-            hipLaunchKernelGGL((k_scan_skip<true, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);           \
-        else if (c->weighted)                                                                                                 \
-            hipLaunchKernelGGL((k_scan_skip<false, true, true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
-        else if (inl)                                                                                                         \
-            hipLaunchKernelGGL((k_scan_skip<true, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);          \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((k_scan_skip<false, true, false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);         \
+            // sparse form: skip index + rewrite of the tiles that pass, a batch of merges per launch.
+            // A grid that is resident all at once (no second round of workgroups behind the first): each thread tests kt
+            // tiles' signatures per merge, a workgroup owns `chunk` consecutive tiles at a time.  Wide workgroups
+            // (full_wpb waves, 16 waves per CU either way): a merge late in a job has its sites in a few word types, so
+            // every workgroup with a site adds to the SAME few table counts -- same-address atomics are served one after
+            // the other, and the queue is as long as there are workgroups; a wider workgroup also evens out how many
+            // matched tiles a wave has to rewrite.  (0 = by the merge: 16 waves once a merge has so few sites that the
+            // queue on the hot counts is what is left -- and the whole stream fits one round of such workgroups -- else 8)
+            if (!sparse) return fail(c, YABPE_E_INTERNAL, "sparse form without signatures");
+            int64_t wpb_opt = optv(c, "full_wpb", 0);
+            if (wpb_opt <= 0)
+                wpb_opt = (c->st_host->best_count <= (unsigned long long)optv(c, "wide_sites_per_cu", 20) * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
+            const uint32_t nw = wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB;
+            const uint32_t nt = nw * 64u;
+            const uint32_t target = (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)));
+            // tiles per workgroup: what fills `target` workgroups, in whole waves of signature tests, at most kt_max per thread
+            const uint32_t ktm = (uint32_t)scan_kt_max((int)nw);
+            const uint32_t chunk = std::min<uint32_t>(nt * ktm, std::max<uint32_t>(64u, (uint32_t)(((uint64_t)(c->n_tiles + target - 1) / target + 63u) / 64u * 64u)));
+            const uint32_t kt = (chunk + nt - 1) / nt;
+            const uint32_t n_chunks = (c->n_tiles + chunk - 1) / chunk;
+            const uint32_t scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n_chunks, target), MAX_LISTS));
+            if (!c->blk_read) {
+                TRY(dmalloc(c, &c->blk_read, MAX_LISTS));
+                HIPCHK(c, hipMemsetAsync(c->blk_read, 0, MAX_LISTS * 8, c->stream));
+            }
+            // (a sparse merge leaves a workgroup a few dozen deltas: a quarter of the aggregator per merge of the batch is
+            // plenty -- less to initialise and to flush; the count of the LAST batch's merges bounds this batch's)
+            if (optv(c, "agg_small", 1) && !c->weighted && c->st_host->best_count * 4 < 48ull * std::max<uint32_t>(1u, c->n_cu * 3))
+                P.agg_mask = (uint32_t)(c->kmax_now > 2 ? AGG_N : nw >= 16 ? AGG_N / 2 : AGG_N / 4) - 1u;
+            ScanSkipParams SQ{P, c->blk_read, scan_grid, kt, chunk, R, fuse_params(scan_grid)};
+            c->blk_used = std::max(c->blk_used, scan_grid);
+            const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
+#define YB_LAUNCH_SPARSE(NW_)                                                                                        \
+    do {                                                                                                             \
+        if (c->weighted)                                                                                             \
+            hipLaunchKernelGGL((k_scan_skip<true, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);      \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_scan_skip<false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);     \
     } while (0)
-                    if (nw == 16) YB_LAUNCH_FULL(16);
-                    else if (nw == 8) YB_LAUNCH_FULL(8);
-                    else YB_LAUNCH_FULL(WPB);
-#undef YB_LAUNCH_FULL
-                    skip_slow = true;
-                } else if (inl && !c->weighted) {
-                    hipLaunchKernelGGL((k_scan_skip<true, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);
-                } else {
-                    hipLaunchKernelGGL((k_scan_skip<false, false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->st, SQ);
-                }
-                c->scan_skip_launches++;
-            } else {
-                scan_grid = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(want, (uint32_t)optv(c, "scan_blocks", (int64_t)c->n_cu * 4)), MAX_LISTS));
-                seg = WPB * ((c->n_tiles + scan_grid * WPB - 1) / (scan_grid * WPB));
-                TRY(ensure_worklist(c, scan_grid, seg));
-                ScanParams SP{c->tiles, c->tile_len, c->n_tiles, c->st, c->work, c->work_cnt, seg};
-                hipLaunchKernelGGL(k_scan, dim3(scan_grid), dim3(BLOCK), 0, c->stream, SP);
-            }
+            if (nw == 16) YB_LAUNCH_SPARSE(16);
+            else if (nw == 8) YB_LAUNCH_SPARSE(8);
+            else YB_LAUNCH_SPARSE(WPB);
+#undef YB_LAUNCH_SPARSE
+            c->scan_skip_launches++;
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
-            if (!skip_slow) {
-            const bool dense = use_sig && c->dense_mode;
-            const uint32_t slow_grid = dense ? std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks_dense", 128)))
-                                             : std::max(1u, std::min<uint32_t>(want, (uint32_t)optv(c, "slow_blocks", (int64_t)c->n_cu * 4)));
-            c->blk_used = std::max(c->blk_used, slow_grid);
-            SlowParams SL{P, c->work, c->work_cnt, scan_grid, seg, dense ? c->work_dense : nullptr, DENSE_CAP};
-            if (c->weighted)
-                hipLaunchKernelGGL(k_slow<true>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
-            else
-                hipLaunchKernelGGL(k_slow<false>, dim3(slow_grid), dim3(BLOCK), 0, c->stream, SL);
-            }
-            }
         }
     } else if (ev) {
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
@@ -1508,9 +1313,9 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, L);
     }
     if (c->multi) {
-        // Per merge: the apply launch above left this rank's updates as [header | records] in its send buffer (the
+        // Per batch: the apply launch above left this rank's updates as [header | records] in its send buffer (the
         // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every
-        // rank's records to the replica and -- fused form -- selects the next merge in its last workgroup.
+        // rank's records to the replica and -- fused form -- selects the next merges in its last workgroup.
         const uint64_t xbytes = 16 + (uint64_t)c->xeff * sizeof(DeltaRec);  // [header | xeff records] per rank, packed at that stride
         TRY(comm_allgather(c, c->xsend, c->xrecv, xbytes));
         c->xeff_sum += c->xeff;
@@ -1530,6 +1335,23 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     return 0;
 }
 
+namespace {
+// the timing events of one yabpe_train call: destroyed on every way out
+struct TrainEvents {
+    hipEvent_t t0 = nullptr, t1 = nullptr, t_split = nullptr, t_tail = nullptr;
+    int create() {
+        return (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess && hipEventCreate(&t_split) == hipSuccess &&
+                hipEventCreate(&t_tail) == hipSuccess) ? 0 : -1;
+    }
+    ~TrainEvents() {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (t_split) (void)hipEventDestroy(t_split);
+        if (t_tail) (void)hipEventDestroy(t_tail);
+    }
+};
+}  // namespace
+
 int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint32_t *out_left, uint32_t *out_right,
                 uint32_t *out_merged, uint64_t *out_count, uint32_t *out_n_merges) {
     if (!c) return YABPE_E_INVALID;
@@ -1538,18 +1360,22 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     if (out_n_merges) *out_n_merges = 0;
     TRY(state_pull(c));
     DevState *h = c->st_host;
-    // The u16 id space bounds the vocabulary at YB_MAX_TOKENS.  The reference has no such bound, and a job that asks for more
-    // merges than that usually stops long before (no pairs left, min_frequency): the request is clamped to one merge past
-    // the last id, and only if the loop really gets there with a pair still to merge does the selection stop it
-    // (HALT_VOCAB_FULL -> YABPE_E_CAPACITY below) -- reported, never silently truncated.
-    if ((uint64_t)h->n_tokens + num_merges > YB_MAX_TOKENS) num_merges = YB_MAX_TOKENS - h->n_tokens + 1;
+    // The u16 id space bounds the vocabulary at YB_MAX_TOKENS; the reference has no such bound (trainer.py:238, 298-300).  A
+    // merge that re-creates the bytes of an existing token takes no id (trainer.py:298), so the number of merges a job can run
+    // is not bounded by the ids that are left: the request stands as it is, and only when the loop needs an id past the last
+    // one does the selection stop it (HALT_VOCAB_FULL -> YABPE_E_CAPACITY below) -- reported, never silently truncated.
+    // Most such jobs end long before (no pairs left, min_frequency); the per-merge records grow as the loop proceeds.
     const uint32_t rec_base = h->iter;
+    if ((uint64_t)rec_base + num_merges > 0xFFFFFFF0ull) return fail(c, YABPE_E_CAPACITY, "more than 2^32 merges in one context");
     h->num_merges = rec_base + num_merges;
     h->min_freq = min_frequency;
     h->done = 0;
     h->halt = 0;
     h->halt_req = 0;
+    h->n_batch = 0;
+    h->kmax = 1;
     TRY(state_push(c));
+    c->kmax_now = 1;
     c->rec_n = 0;
     c->log_sites.clear();
     c->log_live.clear();
@@ -1558,55 +1384,66 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     c->ev_scan_us.clear();
     c->split_mode = false;
     c->sig_valid = false;
-    c->dense_mode = false;
     if (num_merges == 0) return YABPE_OK;
-    if (c->table.dense) {
-        // rows for the tokens this call can create: all of them up front when the corpus is large (it will use them, and a
-        // matrix that grows in steps copies itself each time); small jobs grow as they go (many stop long before the limit)
-        const uint32_t want = h->n_tokens + (c->tokens_initial >= (16ull << 20) ? num_merges : std::min<uint32_t>(num_merges, 1024u)) + 16u;
-        TRY(dense_ensure_rows(c, want));
-    }
 
-    if (c->rec_cap < num_merges) {
+    // per-merge records: a job cannot run more merges than it has ids for plus the (rare) merges that reuse one; room for the
+    // ids, grown below if a job really gets past that
+    auto ensure_records = [&](uint32_t need) -> int {
+        if (c->rec_cap >= need) return 0;
+        const uint32_t ncap = std::max<uint32_t>(need, c->rec_cap + c->rec_cap / 2);
+        uint32_t *nl = nullptr, *nr = nullptr, *nm = nullptr;
+        unsigned long long *nc = nullptr, *ns = nullptr, *nv = nullptr;
+        TRY(dmalloc(c, &nl, ncap)); TRY(dmalloc(c, &nr, ncap)); TRY(dmalloc(c, &nm, ncap));
+        TRY(dmalloc(c, &nc, ncap)); TRY(dmalloc(c, &ns, ncap)); TRY(dmalloc(c, &nv, ncap));
+        HIPCHK(c, hipMemsetAsync(ns, 0, (size_t)ncap * 8, c->stream));
+        if (c->rec_cap && c->rec_n_live) {
+            const size_t n = c->rec_n_live;
+            HIPCHK(c, hipMemcpyAsync(nl, c->rec_left, n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nr, c->rec_right, n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nm, c->rec_merged, n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nc, c->rec_count, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(ns, c->rec_sites, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nv, c->rec_live, n * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         free_records(c);
-        TRY(dmalloc(c, &c->rec_left, num_merges));
-        TRY(dmalloc(c, &c->rec_right, num_merges));
-        TRY(dmalloc(c, &c->rec_merged, num_merges));
-        TRY(dmalloc(c, &c->rec_count, num_merges));
-        TRY(dmalloc(c, &c->rec_sites, num_merges));
-        TRY(dmalloc(c, &c->rec_live, num_merges));
-        c->rec_cap = num_merges;
-    }
-    HIPCHK(c, hipMemsetAsync(c->rec_sites, 0, (size_t)num_merges * 8, c->stream));
+        c->rec_left = nl; c->rec_right = nr; c->rec_merged = nm; c->rec_count = nc; c->rec_sites = ns; c->rec_live = nv;
+        c->rec_cap = ncap;
+        return 0;
+    };
+    c->rec_n_live = 0;
+    const uint32_t rec_first = (uint32_t)std::min<uint64_t>(num_merges, (uint64_t)YB_MAX_TOKENS + 4096);
+    if (c->rec_cap < rec_first) { free_records(c); }
+    TRY(ensure_records(rec_first));
+    HIPCHK(c, hipMemsetAsync(c->rec_sites, 0, (size_t)c->rec_cap * 8, c->stream));
 
     const uint32_t check = (uint32_t)std::max<int64_t>(1, optv(c, "check_interval", 64));
     const uint32_t ev_sample = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample", 0));
     const uint32_t ev_sample_dense = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample_dense", (int64_t)ev_sample));  // fused k_apply launches
     const double retile_frac = (double)optv(c, "retile_pct", 60) / 100.0;
     const uint64_t retile_min_tiles = (uint64_t)optv(c, "retile_min_tiles", 4096);
-    std::vector<EventPair> used_events;
     size_t ev_next = 0;
 
-    hipEvent_t t0, t1, t_split, t_tail;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
-    HIPCHK(c, hipEventCreate(&t_split));
-    HIPCHK(c, hipEventCreate(&t_tail));
-    HIPCHK(c, hipEventRecord(t0, c->stream));
+    TrainEvents T;
+    if (T.create() != 0) return fail(c, YABPE_E_HIP, "event creation failed");
+    HIPCHK(c, hipEventRecord(T.t0, c->stream));
     bool split_marked = false, tail_marked = false;
     uint32_t split_at = 0, tail_at = 0;
 
-    uint32_t tokens_start = h->n_tokens;
-    uint32_t i = 0;
+    uint32_t i = 0;  // merges selected so far in this call (read back from the device between batches of launches)
     bool finished = false;
     bool skip_cand_once = false;
+    bool first_round = true;
     unsigned long long prev_best = 0;
+    uint64_t launches_sparse = 0;
+    uint32_t cand_n_all = 0;  // length of the candidate list at the last read (multi-GPU: of the longest replica's)
     c->use_cand = false;
     c->pending = false;
     while (!finished) {
         // (re)size the argmax grid to the table
         uint32_t want_partials = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / (BLOCK * 8)));
         if (want_partials != c->n_partials) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
             dfree(c->partials);
             c->partials = nullptr;
             c->n_partials_cap = std::max<uint32_t>(want_partials, 64);
@@ -1615,7 +1452,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         }
         const uint32_t apply_grid = count_grid(c);
         // sites per merge never increase (the best count is monotone): once they are sparse relative to the
-        // number of tiles, switch from the fused kernel to scan + balanced rewrite for good
+        // number of tiles, switch from the streaming kernel to the skip index + rewrite for good
         const int64_t split_opt = optv(c, "split", -1);  // -1 auto, 0 never, 1 always
         if (split_opt >= 0)
             c->split_mode = split_opt == 1;
@@ -1623,20 +1460,16 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         else if (!c->split_mode && h->iter > rec_base &&
                  (c->weighted && h->sites ? h->sites : h->best_count) * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
             c->split_mode = true;
+        if (!c->n_tiles) c->split_mode = false;
         if (!tail_marked && i >= num_merges / 2) {  // (measurement: the second half of this call's merges)
             tail_marked = true;
             tail_at = i;
-            HIPCHK(c, hipEventRecord(t_tail, c->stream));
+            HIPCHK(c, hipEventRecord(T.t_tail, c->stream));
         }
         if (c->split_mode && !split_marked) {  // (measurement: where the streaming phase ends and the sparse phase begins)
             split_marked = true;
             split_at = i;
-            HIPCHK(c, hipEventRecord(t_split, c->stream));
-        }
-        {
-            const double lam = c->n_tiles ? (double)h->best_count / (double)c->n_tiles : 0.0;
-            const int64_t dm = optv(c, "dense_worklist", -1);  // -1 auto, 0 never, 1 always
-            c->dense_mode = dm >= 0 ? dm == 1 : (c->split_mode && h->iter > rec_base && lam * lam * 0.5 * (double)c->n_tiles < (double)optv(c, "dense_multi", 1ll << 40));
+            HIPCHK(c, hipEventRecord(T.t_split, c->stream));
         }
         if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
             c->use_cand = false;
@@ -1652,27 +1485,40 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // selection is one workgroup reading all of it.
             const unsigned long long drop = prev_best > h->best_count ? prev_best - h->best_count : 0;
             const bool near_T = h->best_count < c->table.cand_T + 2 * drop + 1;
-            const bool long_list = h->cand_n > std::max<uint32_t>(4u * BLOCK - 64u, (uint32_t)optv(c, "cand_target", 768));  // (one pass of the fused selection: 4 entries per thread)
-            if (!c->use_cand || i - c->cand_built_at >= every || near_T || long_list) {
+            // (multi-GPU: a pair can be listed more often on one replica than on another -- the longest list decides for all,
+            // every rank must rebuild at the same merges or their thresholds T drift apart)
+            const bool long_list = cand_n_all > std::max<uint32_t>(4u * BLOCK - 64u, (uint32_t)optv(c, "cand_target", 768));  // (one pass of the fused selection: 4 entries per thread)
+            if (!c->use_cand || i - c->cand_built_at >= every || i < c->cand_built_at || near_T || long_list) {
                 TRY(cand_rebuild(c, h->best_count));
                 c->cand_built_at = i;
                 c->cand_best_at_build = h->best_count;
             }
             prev_best = h->best_count;
         }
-        if (c->split_mode && optv(c, "skip_index", 1)) {
-            // signatures are built when the split form starts and refreshed now and then (rewrites only ever ADD bits)
+        if (c->split_mode) {
+            // signatures are built when the sparse form starts and refreshed now and then
             // (rewrites only ever ADD bits: every merged site leaves up to two new pairs and three stale ones behind)
             const uint32_t every = (uint32_t)std::max<int64_t>(1, optv(c, "sig_rebuild_every", 16384));
             const uint64_t merged_since = c->sig_tokens_at_build > h->tokens_now ? c->sig_tokens_at_build - h->tokens_now : 0;
             const bool stale = merged_since * 100 > c->sig_tokens_at_build * (uint64_t)optv(c, "sig_rebuild_pct", 20);
-            if (!c->sig_valid || i - c->sig_built_at >= every || stale) {
+            if (!c->sig_valid || i - c->sig_built_at >= every || i < c->sig_built_at || stale) {
                 TRY(build_signatures(c));
                 c->sig_valid = true;
                 c->sig_built_at = i;
             }
         }
-        uint32_t batch_end = std::min(num_merges, i + ((i == 0 && !c->split_mode) ? std::min<uint32_t>(check, 8) : check));
+        // merges one selection may take: a batch in the sparse form (the streaming form applies one merge per launch)
+        const uint32_t kmax = c->split_mode ? (uint32_t)std::max<int64_t>(1, std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX))) : 1u;
+        if (kmax != c->kmax_now) {
+            HIPCHK(c, hipMemcpyAsync(&c->st->kmax, &kmax, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            c->kmax_now = kmax;
+            h->kmax = kmax;
+        }
+        // records for everything the launches of this round can select
+        const uint32_t n_launch = (first_round && !c->split_mode) ? std::min<uint32_t>(check, 8) : check;
+        first_round = false;
+        c->rec_n_live = i;
+        TRY(ensure_records((uint32_t)std::min<uint64_t>(num_merges, (uint64_t)i + (uint64_t)(n_launch + 2) * kmax)));
         auto sample = [&](uint32_t iter_rel) -> EventPair * {
             const uint32_t every = c->split_mode ? ev_sample : ev_sample_dense;
             if (!every || (iter_rel % every) != 0) return nullptr;
@@ -1684,30 +1530,36 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->events[ev_next].iter_rel = iter_rel;
             return &c->events[ev_next++];
         };
-        // i = merges whose selection has been launched.  Fused form: one launch applies merge i - 1 and selects merge i;
-        // otherwise a merge is a selection launch followed by its apply launch(es).
+        // Fused form: one launch applies the pending merges and selects the next ones; otherwise a merge is a selection
+        // launch followed by its apply launch(es).  `i` counts selected merges exactly while one launch selects one merge
+        // (streaming form, unfused); in the sparse form a launch selects a batch and `i` is a lower bound until the next read.
         const bool fuse = can_fuse(c);
-        if (c->table.dense && !c->use_cand)  // the fallback argmax scans rows: list them once for the whole batch
-            TRY(dense_list_rows(c, h->n_tokens, 1, (batch_end > i ? batch_end - i : 0) + 2));
-        if (c->pending && (!fuse || i >= num_merges)) {  // leave the fused form: the selected merge is applied on its own
-            TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i - 1), false));
+        const uint32_t tok_upper0 = h->n_tokens;
+        uint32_t launched = 0;
+        if (c->pending && (!fuse || i >= num_merges)) {  // leave the fused form: the selected merges are applied on their own
+            TRY(launch_apply(c, rec_base, tok_upper0 + kmax, apply_grid, sample(i ? i - 1 : 0), false));
             c->pending = false;
         }
-        if (fuse && !c->pending && i < batch_end) {  // enter it: a selection on its own
+        if (fuse && !c->pending && i < num_merges) {  // enter it: a selection on its own
             TRY(launch_select(c, rec_base));
             c->pending = true;
             ++i;
         }
-        for (; i < batch_end; ++i) {
+        for (uint32_t l = 0; l < n_launch && i < num_merges + (fuse ? 1u : 0u); ++l) {
+            ++launched;
+            const uint32_t tok_upper = tok_upper0 + (launched + 1u) * kmax + 1u;
             if (fuse) {
-                TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i - 1), true));
+                TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i - 1), true));
+                if (kmax == 1) ++i; else ++launches_sparse;
             } else {
                 TRY(launch_select(c, rec_base));
-                TRY(launch_apply(c, rec_base, tokens_start + i + 1, apply_grid, sample(i), false));
+                TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i), false));
+                ++i;
             }
         }
         TRY(fold_stats(c));
         TRY(state_pull(c));
+        i = h->iter - rec_base;                              // what the device really selected
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
         if (h->done || h->halt) c->pending = false;          // the last selection of the batch did not select
         if (c->multi && c->xrecv) {
@@ -1729,17 +1581,20 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             HIPCHK(c, hipMemsetAsync(&c->st->xmax, 0, sizeof(uint32_t), c->stream));
             h->xmax = 0;
         }
+        cand_n_all = h->cand_n;
         if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
             unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
             TRY(comm_max(c, sig, &mx));
             if (mx != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, mx);
+            unsigned long long cn_all = 0;
+            TRY(comm_max(c, h->cand_n, &cn_all));
+            cand_n_all = (uint32_t)cn_all;
         }
         if (h->halt == HALT_RESCAN) {  // the candidate set could not prove the maximum: redo that merge with the full scan
             h->halt = 0; h->halt_req = 0;
             TRY(state_push(c));
             c->cand_rescans++;
             skip_cand_once = true;
-            i = h->iter - rec_base;
             while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;  // those launches did nothing: timed again in the re-run
             continue;
         }
@@ -1764,17 +1619,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;
                 continue;
             }
-            if (h->halt == HALT_MATRIX_ROWS) {  // (the net under the row growth between batches: nothing was selected)
-                h->halt = 0; h->halt_req = 0;
-                TRY(state_push(c));
-                TRY(dense_ensure_rows(c, h->n_tokens + 2 * check + 16));
-                i = h->iter - rec_base;
-                continue;
-            }
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
                               : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
                                                            : "device halt";
-            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(t_split); (void)hipEventDestroy(t_tail);
             return fail(c, YABPE_E_CAPACITY, "%s after %u merges", why, h->iter - rec_base);
         }
         if (h->done || (i >= num_merges && !c->pending)) {
@@ -1785,35 +1632,30 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         // kept at 12-30 % load: a key that is not at its home slot costs the flush of every merge a dependent trip (the
         // 1 GiB job: 1.60 s at 50-70 % load, 1.42 s at 12-30 %), and the table is scanned only now and then (candidate
         // rebuilds).  Same decision on every rank.
-        if (c->table.dense)  // rows for the tokens the next batches will create
-            TRY(dense_ensure_rows(c, h->n_tokens + 2 * check + 16));
-        else if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
+        if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
             TRY(table_grow(c, std::max<uint64_t>(h->table_entries * (uint64_t)std::max<int64_t>(2, optv(c, "table_grow_x", 8)), 1ull << 16)));
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
             TRY(retile_flat(c));
         }
     }
-    HIPCHK(c, hipEventRecord(t1, c->stream));
-    HIPCHK(c, hipEventSynchronize(t1));
+    HIPCHK(c, hipEventRecord(T.t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(T.t1));
     float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    HIPCHK(c, hipEventElapsedTime(&ms, T.t0, T.t1));
     if (split_marked) {
         float sms = 0;
-        HIPCHK(c, hipEventElapsedTime(&sms, t_split, t1));
+        HIPCHK(c, hipEventElapsedTime(&sms, T.t_split, T.t1));
         c->stats.sparse_ms += sms;
         c->stats.sparse_merges += (h->iter - rec_base) > split_at ? (h->iter - rec_base) - split_at : 0;
+        c->stats.sparse_launches += launches_sparse;
     }
     if (tail_marked) {
         float tms = 0;
-        HIPCHK(c, hipEventElapsedTime(&tms, t_tail, t1));
+        HIPCHK(c, hipEventElapsedTime(&tms, T.t_tail, T.t1));
         c->stats.tail_ms += tms;
         c->stats.tail_merges += (h->iter - rec_base) > tail_at ? (h->iter - rec_base) - tail_at : 0;
     }
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
-    (void)hipEventDestroy(t_split);
-    (void)hipEventDestroy(t_tail);
     c->stats.train_ms += ms;
 
     // close the log of the last iteration and fold the remaining sites into T_i
@@ -1833,12 +1675,12 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     TRY(state_push(c));
     // algorithmic bytes: A_i = 2 * (T_i + W)
     {
-        uint64_t T = tokens_at_start;
+        uint64_t T_ = tokens_at_start;
         std::vector<uint64_t> Ti(n);
         for (uint32_t k = 0; k < n; ++k) {
-            Ti[k] = T;
-            c->stats.algo_bytes_total += 2 * (T + c->n_words_input);
-            T -= c->log_sites[k];
+            Ti[k] = T_;
+            c->stats.algo_bytes_total += 2 * (T_ + c->n_words_input);
+            T_ -= c->log_sites[k];
         }
         for (size_t e = 0; e < ev_next; ++e) {
             uint32_t k = c->events[e].iter_rel;
@@ -1851,13 +1693,13 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->ev_us.push_back(ems * 1000.0f);
             c->ev_scan_us.push_back(sms * 1000.0f);
             c->stats.apply_launches_sampled += 1;
-            if (!c->events[e].split) {  // fused k_apply: one streaming pass over the live stream + rewrite (+ selection when fused)
+            if (!c->events[e].split) {  // streaming form: one pass over the live stream + rewrite (+ selection when fused), one merge
                 c->stats.dense_ms_sampled += ems;
                 c->stats.dense_launches_sampled += 1;
                 c->stats.dense_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
                 c->stats.dense_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
             }
-            if (c->events[e].split) {
+            if (c->events[e].split) {  // (sparse form: the merge index of a sampled launch is a lower bound -- launches select batches)
                 c->stats.scan_ms_sampled += sms;
                 c->stats.scan_launches_sampled += 1;
                 c->stats.scan_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
@@ -2009,24 +1851,6 @@ int yabpe_verify_table(yabpe_ctx *c, uint64_t *out_mismatches) {
     if (!c->have_words) return fail(c, YABPE_E_INVALID, "no corpus loaded");
     PairTable scratch{};
     HIPCHK(c, hipMemsetAsync(&c->scratch64[4], 0, 16, c->stream));  // [4] entries, [5] mismatches
-    if (c->table.dense) {  // recount into a second matrix over the same tokens, compare entry by entry
-        TRY(state_pull(c));
-        const uint32_t n_tok = c->st_host->n_tokens;
-        TRY(dense_alloc(c, scratch, n_tok));
-        scratch.entries = &c->scratch64[4];
-        TRY(launch_count(c, scratch));
-        const unsigned long long n = tri_size(n_tok);
-        hipLaunchKernelGGL(k_dense_compare, dim3((uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, n / BLOCK))), dim3(BLOCK), 0, c->stream,
-                           c->table.dense, scratch.dense, n, &c->scratch64[5]);
-        HIPCHK(c, hipGetLastError());
-        unsigned long long mmd = 0;
-        HIPCHK(c, hipMemcpyAsync(&mmd, &c->scratch64[5], 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        table_free(scratch);
-        HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, 4, c->stream));
-        *out_mismatches = mmd;
-        return YABPE_OK;
-    }
     TRY(table_alloc(c, scratch, c->table_cap, &c->scratch64[4]));
     TRY(launch_count(c, scratch));
     uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / BLOCK));

@@ -41,10 +41,13 @@ constexpr int MAX_LISTS_PROF = 4096;
 constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined by one workgroup at a time (x kt)
 constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
 constexpr int scan_kt_max(int nw) { return nw >= 16 ? 2 : 4; } // (a workgroup's hit list lives in LDS: 64 * nw * kt entries)
-constexpr int SCAN_HITS_LDS = 1024;  // k_scan: hits buffered per workgroup before they are stored
 
-enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5, HALT_MATRIX_ROWS = 6 };
+enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
 
+constexpr int KMAX = 8; // merges one sparse launch applies at most (a batch, see select_batch)
+struct BatchMerge {
+    uint32_t a, b, c, is_new; // the pair, the merged token, whether the merge created it
+};
 struct DevState {
     uint32_t iter;       // merges recorded so far
     uint32_t done;       // stop rule hit
@@ -63,9 +66,10 @@ struct DevState {
     unsigned long long tokens_now; // T_i
     unsigned long long delta_entries;
     unsigned long long best_count; // count of the merge being applied
-    uint32_t chunk_next[8];        // k_apply_skip: dynamic chunk queues (sharded 8 ways), reset by k_select
-    uint32_t work_total;           // dense worklist: items appended by k_scan_skip this merge (reset by k_select)
     uint32_t xmax;                 // multi-GPU: the largest record count any rank has sent since the host cleared this (k_delta_apply)
+    uint32_t kmax;                 // merges the next selection may put in one batch (1: the streaming form applies one merge per launch)
+    uint32_t n_batch;              // merges selected and not applied yet: batch[0 .. n_batch), in selection order; a, b, c above = batch[0]
+    BatchMerge batch[KMAX];
 };
 
 // multi-GPU exchange records: what a rank's apply pass sends to the others (see k_delta_apply)
@@ -102,23 +106,7 @@ struct PairTable {
     DeltaRec *sink_rec;
     DeltaHdr *sink_hdr;
     uint32_t sink_cap;
-    // Direct-indexed form (the main table by default): dense != NULL -- one u64 count per POSSIBLE pair of the dense_v tokens
-    // the matrix has rows for, no keys, no probing, no inserts (keys / cnt / cap are unused).  Pair (x, y) belongs
-    // to the row of its YOUNGER token o = max(x, y): row o holds the 2 (o + 1) pairs (o, j <= o) and (j < o, o), rows are
-    // stored one after the other (row o starts at o (o + 1)).  A merge only ever CREATES adjacencies with the token it has
-    // just made, so all the counts that go up in a merge lie in that one new row, and a row never grows after the merge
-    // that made its token: rowmax[o] (set by the selection, refreshed by scans) bounds it from above and lets scans skip rows.
-    // 288 GB of HBM is what makes this layout the natural one here: 8.3 GB for 32k merges, 34 GB at the u16 id limit.
-    unsigned long long *dense;
-    unsigned long long *rowmax;
-    uint32_t dense_v;
 };
-YB_HD unsigned long long tri_idx(uint32_t key) {
-    const unsigned long long x = key >> 16, y = key & 0xffffu;
-    return x >= y ? x * (x + 1ull) + y : y * (y + 1ull) + y + 1ull + x;
-}
-YB_HD unsigned long long tri_size(uint32_t v) { return (unsigned long long)v * ((unsigned long long)v + 1ull); } // entries of rows 0 .. v-1
-YB_HD uint32_t tri_key(uint32_t o, uint32_t j) { return j <= o ? ((o << 16) | j) : (((j - o - 1u) << 16) | o); } // entry j of row o
 __device__ __forceinline__ uint32_t hash32(uint32_t k);
 __device__ __forceinline__ uint32_t pt_home(const PairTable &t, uint32_t key) { // fast range reduction of the hash
     return (uint32_t)(((unsigned long long)hash32(key) * t.cap) >> 32);
@@ -255,33 +243,10 @@ __device__ __forceinline__ void cand_note(const PairTable &t, uint32_t s, uint32
     else
         st_coherent(&t.cand_cs->overflow, 1u);
 }
-// the count of `key` (dense form), or of the slot an entry of the candidate list names
-__device__ __forceinline__ unsigned long long *pt_count_ptr(const PairTable &t, unsigned long long entry) {
-    return t.dense ? &t.dense[tri_idx((uint32_t)(entry >> 32))] : &t.cnt[(uint32_t)entry];
-}
-// dense form: count(key) += d.  A count that crosses the threshold of the candidate argmax on its way up joins the list
-// (exactly one adder sees the crossing; a pair that falls below and crosses again is listed twice, which is harmless).
-__device__ __forceinline__ void gt_bump_dense(const PairTable &t, uint32_t key, long long d) {
-    unsigned long long *p = &t.dense[tri_idx(key)];
-    if (d > 0 && t.cand_list) {
-        const unsigned long long old = atomicAdd(p, (unsigned long long)d), now = old + (unsigned long long)d;
-        if ((long long)old < (long long)t.cand_T && (long long)now >= (long long)t.cand_T && (long long)now > 0) {
-            const uint32_t idx = atomicAdd(&t.cand_cs->n, 1u);
-            if (idx < CAND_CAP)
-                st_coherent(&t.cand_list[idx], (unsigned long long)key << 32);
-            else
-                st_coherent(&t.cand_cs->overflow, 1u);
-        }
-    } else {
-        atomicAdd(p, (unsigned long long)d);
-    }
-}
+// the count of the slot an entry of the candidate list names
+__device__ __forceinline__ unsigned long long *pt_count_ptr(const PairTable &t, unsigned long long entry) { return &t.cnt[(uint32_t)entry]; }
 // cnt[s] += d
 __device__ __forceinline__ void gt_bump(const PairTable &t, uint32_t s, uint32_t key, long long d) {
-    if (t.dense) {
-        gt_bump_dense(t, key, d);
-        return;
-    }
     if (d > 0 && t.cand_list) {
         const unsigned long long old = atomicAdd(&t.cnt[s], (unsigned long long)d);
         cand_note(t, s, key, old, old + (unsigned long long)d);
@@ -299,10 +264,6 @@ __device__ __forceinline__ void sink_append(const PairTable &t, uint32_t key, lo
 __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t s, uint32_t *inserted) {
     if (t.sink_rec) {
         sink_append(t, key, d);
-        return;
-    }
-    if (t.dense) {
-        gt_bump_dense(t, key, d);
         return;
     }
     for (uint32_t probe = 0; probe < t.max_probe; ++probe) {
@@ -324,7 +285,7 @@ __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, ui
     atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
 }
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
-    gt_add_from(t, st, key, d, (t.sink_rec || t.dense) ? 0u : pt_home(t, key), inserted);
+    gt_add_from(t, st, key, d, t.sink_rec ? 0u : pt_home(t, key), inserted);
 }
 
 #ifdef YB_PROFILE_SCAN
@@ -448,12 +409,9 @@ struct FlushEnt {
     long long val;
 };
 template <int NT, int N_ENT, class GetF>
-__device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+__device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevState *st) {
     // every thread owns AGG_N / NT entries; the table keys at their home slots are requested together, so that the
-    // usual case (the key sits at its home slot) costs one round trip for all of them.  newtok: the token this merge
-    // created (EMPTY: none) -- a pair that contains it cannot be in the table yet, so its home slot is claimed with the
-    // compare-and-swap right away instead of being looked at first (one dependent trip fewer for half of a sparse
-    // merge's deltas: every site brings two such pairs).
+    // usual case (the key sits at its home slot) costs one round trip for all of them.
     constexpr int PER = (N_ENT + NT - 1) / NT;
     uint32_t k[PER], home[PER], tk[PER];
     long long v[PER];
@@ -496,16 +454,6 @@ __device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevS
         __syncthreads(); // (s_wtot / s_sbase are read above: the direct-indexed store calls this once per role, back to back)
         return;
     }
-    if (t.dense) { // direct-indexed counts: every delta is ONE atomic, nothing to look up first
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = threadIdx.x + q * NT;
-            if (i >= N_ENT) continue;
-            const FlushEnt e = get(i);
-            if (e.key != EMPTY && e.val != 0) gt_bump_dense(t, e.key, e.val);
-        }
-        return;
-    }
     YB_FLUSH_WAIT_STAMP(0);
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -525,15 +473,7 @@ __device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevS
         tk[q] = EMPTY;
         if (v[q] != 0) {
             home[q] = pt_home(t, k[q]);
-            if ((k[q] >> 16) == newtok || (k[q] & 0xffffu) == newtok) {
-                tk[q] = atomicCAS(&t.keys[home[q]], EMPTY, k[q]);
-                if (tk[q] == EMPTY) {
-                    tk[q] = k[q];
-                    ++ins;
-                }
-            } else {
-                tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            tk[q] = __hip_atomic_load(&t.keys[home[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     YB_FLUSH_WAIT_STAMP(1);
@@ -569,13 +509,13 @@ __device__ __forceinline__ void flush_entries(GetF get, const PairTable &t, DevS
 }
 
 template <class V, int NT = BLOCK> // NT: threads of the workgroup
-__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+__device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState *st) {
     flush_entries<NT, AGG_N>(
         [&](int i) -> FlushEnt {
             if ((uint32_t)i > g.mask) return FlushEnt{EMPTY, 0ll};
             return FlushEnt{g.keys[i], (long long)g.vals[i]};
         },
-        t, st, newtok);
+        t, st);
 }
 
 // Direct-indexed form of the per-workgroup delta store, for the first merges of a job (few tokens, many sites per tile):
@@ -589,7 +529,7 @@ struct Hist {
 __device__ __forceinline__ void hist_init(Hist H) {
     for (int i = threadIdx.x; i < 4 * HIST_V; i += BLOCK) H.h[i] = 0;
 }
-__device__ __forceinline__ void hist_flush(Hist H, uint32_t a, uint32_t b, uint32_t c, const PairTable &t, DevState *st, uint32_t newtok = EMPTY) {
+__device__ __forceinline__ void hist_flush(Hist H, uint32_t a, uint32_t b, uint32_t c, const PairTable &t, DevState *st) {
     // one role at a time (two entries per thread): eight entries per thread in one go do not stay in registers
 #pragma unroll 1
     for (uint32_t role = 0; role < 4; ++role) {
@@ -600,7 +540,7 @@ __device__ __forceinline__ void hist_flush(Hist H, uint32_t a, uint32_t b, uint3
                 const uint32_t key = role < 2 ? yb_pairkey((uint32_t)i, fixed) : yb_pairkey(fixed, (uint32_t)i);
                 return FlushEnt{v ? key : EMPTY, (long long)v};
             },
-            t, st, newtok);
+            t, st);
     }
 }
 
@@ -745,7 +685,6 @@ struct ApplyParams {
     unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
     unsigned long long *sig;       // tile signatures (may be NULL)
     uint32_t sig_stride;
-    uint32_t cas_first;            // flush: claim the home slot of a pair that contains the new token without looking first
     uint32_t agg_mask;             // k_scan_skip: LDS aggregator entries in use - 1 (a power of two - 1, <= AGG_N - 1)
     uint32_t stats_fresh;          // 1: this launch is the only one of its merge that writes blk_stats (the selection cleared them):
                                    // a workgroup stores its counters without reading the slot first (a dependent load in front of every flush)
@@ -929,10 +868,13 @@ __device__ unsigned long long g_ss_prof[8];
 // No LDS staging, no bitmaps, no scatter.
 // WEIGHTED (pooled words): the site's word carries a frequency -- the word's index is tile_wbase + the number of SEP slots in
 // front of the site, counted in registers; nothing but the b leaves the tile (words are never dropped in this layout).
-template <class AggV, bool HIST = false, bool WEIGHTED = false>
-__device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile, uint32_t len, const TileRegs &r,
+// DEFER (batched sparse launch: several merges may rewrite the same tile one after the other): nothing is stored -- the
+// rewritten tile replaces `r`, `len` becomes its new length and `first_changed` the first slot that differs from HBM; the
+// caller writes the tile back once, after the last merge of the batch has seen it.
+template <class AggV, bool HIST = false, bool WEIGHTED = false, bool DEFER = false>
+__device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile, uint32_t &len, TileRegs &r,
                                                  int lane_s, uint32_t mm_s, unsigned long long &wave_sites,
-                                                 unsigned long long &wave_freed) {
+                                                 unsigned long long &wave_freed, uint32_t &first_changed) {
     const ApplyParams &P = C.P;
     DevState *st = C.st;
     const uint32_t a = C.a, b = C.b, c = C.c;
@@ -970,6 +912,9 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     const uint32_t new_len = len - (uint32_t)s;
     const uint32_t pad_end = (new_len + 7u) & ~7u;
     uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+    (void)wb;
+    (void)pad_end;
+    uint4 ra = r.va, rb = r.vb; // DEFER: the rewritten tile
     // the first dwords of segment B (for segment A's lane 63)
     const uint32_t fx = __builtin_amdgcn_readfirstlane(r.vb.x), fy = __builtin_amdgcn_readfirstlane(r.vb.y);
     const uint32_t fz = __builtin_amdgcn_readfirstlane(r.vb.z);
@@ -1015,9 +960,20 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
             return (U & m) | (S & ~m);
         };
         const uint4 o = make_uint4(mix(U0, S0, 0), mix(U1, S1, 1), mix(U2, S2, 2), mix(U3, S3, 3));
-        if (g0 + 8 > p && (uint32_t)g0 < pad_end) wb[(seg ? 64 : 0) + lane] = o; // groups from the first changed slot on
+        if constexpr (DEFER) {
+            if (seg) rb = o; else ra = o; // (a group in front of the site comes out unchanged: bd >= 8 keeps every slot)
+        } else {
+            if (g0 + 8 > p && (uint32_t)g0 < pad_end) wb[(seg ? 64 : 0) + lane] = o; // groups from the first changed slot on
+        }
     }
-    if (lane == 0) P.tile_len[tile] = new_len;
+    if constexpr (DEFER) {
+        r.va = ra;
+        r.vb = rb;
+        len = new_len;
+        first_changed = min(first_changed, (uint32_t)p);
+    } else {
+        if (lane == 0) P.tile_len[tile] = new_len;
+    }
     YB_SS_STAMP(4);
     // the two pairs this site creates are now present in the tile: one signature word each, set by lanes 0 and 1
 #ifdef YB_DBG_NOSIGSET
@@ -1048,10 +1004,12 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
 // Rewrites one tile that contains at least one candidate site: pair-count deltas, drop bitmap, compaction,
 // write-back.  Work is proportional to the number of sites.  Returns false when nothing changed.
 // HAVE_MASKS: the caller has the candidate masks of the two segments already (match_mask8): pmA, pmB.
-template <bool WEIGHTED, class AggV, bool HIST = false, bool HAVE_MASKS = false>
-__device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t len, const TileRegs &r,
+// DEFER: see single_site_tile -- the compacted tile is read back from the LDS image into `r` instead of being stored.
+template <bool WEIGHTED, class AggV, bool HIST = false, bool HAVE_MASKS = false, bool DEFER = false>
+__device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t tile, uint32_t &len_io, TileRegs &r,
                                           uint32_t na, uint32_t nb, unsigned long long &wave_sites,
-                                          unsigned long long &wave_freed, uint32_t pmA = 0u, uint32_t pmB = 0u) {
+                                          unsigned long long &wave_freed, uint32_t &first_changed, uint32_t pmA = 0u, uint32_t pmB = 0u) {
+    const uint32_t len = len_io;
     const ApplyParams &P = C.P;
     DevState *st = C.st;
     const uint32_t a = C.a, b = C.b, c = C.c, mk = C.mk, self = C.self;
@@ -1075,7 +1033,7 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s);
                 if (__popc(mm_s) == 1) {
-                    single_site_tile<AggV, HIST>(C, tile, len, r, lane_s, mm_s, wave_sites, wave_freed);
+                    single_site_tile<AggV, HIST, false, DEFER>(C, tile, len_io, r, lane_s, mm_s, wave_sites, wave_freed, first_changed);
                     return true;
                 }
             }
@@ -1223,10 +1181,19 @@ __device__ __forceinline__ bool slow_tile(SlowCtx<AggV> &C, WaveLds &W, uint32_t
     if (lane < 8 && new_len + lane < pad_end) outb[new_len + lane] = YB_PAD;
     wave_sync();
     YB_STAMP(3);
-    uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-    if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(outb + pA);
-    if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(outb + pB);
-    if (lane == 0) P.tile_len[tile] = new_len;
+    if constexpr (DEFER) {
+        const uint4 pp = make_uint4(PADPAD, PADPAD, PADPAD, PADPAD);
+        r.va = (uint32_t)pA < new_len ? *reinterpret_cast<const uint4 *>(outb + pA) : pp;
+        r.vb = (uint32_t)pB < new_len ? *reinterpret_cast<const uint4 *>(outb + pB) : pp;
+        len_io = new_len;
+        first_changed = min(first_changed, first_drop);
+        wave_sync(); // (the image is read: the next rewrite of this wave may stage over it)
+    } else {
+        uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+        if ((uint32_t)pA < new_len && (uint32_t)pA + 8 > first_drop) wb[lane] = *reinterpret_cast<const uint4 *>(outb + pA);
+        if ((uint32_t)pB < new_len && (uint32_t)pB + 8 > first_drop) wb[64 + lane] = *reinterpret_cast<const uint4 *>(outb + pB);
+        if (lane == 0) P.tile_len[tile] = new_len;
+    }
     wave_freed += dropped;
     YB_STAMP(4);
     return true;
@@ -1249,7 +1216,7 @@ __device__ __forceinline__ void wave_lds_init(WaveLds &W, int lane) {
 // per-workgroup epilogue shared by k_apply and k_slow: counters by plain stores, deltas to the table
 template <class AggV, int NT = BLOCK>
 __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> agg, DevState *st, unsigned long long *s_cnt,
-                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane, uint32_t newtok = EMPTY,
+                                               unsigned long long wave_sites, unsigned long long wave_freed, int lane,
                                                int *hist = nullptr, uint32_t ha = 0, uint32_t hb = 0, uint32_t hc = 0) {
     if (lane == 0) {
         if (wave_sites) atomicAdd(&s_cnt[0], wave_sites);
@@ -1266,77 +1233,24 @@ __device__ __forceinline__ void apply_epilogue(const ApplyParams &P, Agg<AggV> a
         }
     }
     if (hist) // (the direct-indexed store of merge (ha, hb) -> hc)
-        hist_flush(Hist{hist}, ha, hb, hc, P.out, st, newtok);
+        hist_flush(Hist{hist}, ha, hb, hc, P.out, st);
     else
-        agg_flush<AggV, NT>(agg, P.out, st, newtok);
-}
-
-// ---------------------------------------------------------------- split form, pass 1: pure streaming scan
-// Reads the live token stream once (the roofline pass) and records which tiles contain the pair.  No LDS
-// tables, few registers; every workgroup appends to its own segment of the worklist: no global atomics.
-struct ScanParams {
-    const uint16_t *tiles;
-    const uint32_t *tile_len;
-    uint32_t n_tiles;
-    DevState *st;
-    uint2 *work;        // [gridDim.x * seg] (tile id, live length)
-    uint32_t *work_cnt; // [gridDim.x]
-    uint32_t seg;
-};
-
-__global__ __launch_bounds__(BLOCK) void k_scan(ScanParams P) {
-    __shared__ uint32_t s_n;
-    __shared__ uint2 s_hl[SCAN_HITS_LDS]; // hits are buffered here: a store inside the loop would queue in front of the
-                                          // wave's prefetched loads (stores and loads share the in-order vmcnt)
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    const uint32_t mk = yb_memkey(st->a, st->b);
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
-    const uint32_t stride = gridDim.x * WPB;
-    const uint32_t n_tiles = P.n_tiles;
-    for (uint32_t batch = blockIdx.x * WPB + wib; batch < n_tiles; batch += stride * 64u) {
-        const unsigned long long my_tile = (unsigned long long)batch + (unsigned long long)lane * stride;
-        const uint32_t my_len = my_tile < n_tiles ? P.tile_len[my_tile] : 0u;
-        const uint32_t cnt = min(64u, (n_tiles - batch + stride - 1) / stride);
-        TileRegs q0 = load_tile(P.tiles, batch, __builtin_amdgcn_readlane(my_len, 0), lane);
-        TileRegs q1 = q0;
-        if (cnt > 1) q1 = load_tile(P.tiles, batch + stride, __builtin_amdgcn_readlane(my_len, 1), lane);
-        for (uint32_t i = 0; i < cnt; ++i) { // two tiles in flight per wave
-            const uint32_t tile = batch + i * stride;
-            const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
-            const TileRegs r = q0;
-            q0 = q1;
-            if (i + 2 < cnt) q1 = load_tile(P.tiles, tile + 2 * stride, __builtin_amdgcn_readlane(my_len, i + 2), lane);
-            if (len == 0) continue;
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            if (lane == 0) {
-                const uint32_t idx = atomicAdd(&s_n, 1u);
-                if (idx < (uint32_t)SCAN_HITS_LDS)
-                    s_hl[idx] = make_uint2(tile, len);
-                else
-                    my_work[idx] = make_uint2(tile, len);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t nh = min(s_n, (uint32_t)SCAN_HITS_LDS);
-    for (uint32_t i = threadIdx.x; i < nh; i += BLOCK) my_work[i] = s_hl[i];
-    if (threadIdx.x == 0) P.work_cnt[blockIdx.x] = s_n;
+        agg_flush<AggV, NT>(agg, P.out, st);
 }
 
 // ---------------------------------------------------------------- token byte strings on the device
-struct TokRec {      // 16 B per token: what the selection needs about a token, in one place
+struct TokRec {      // 32 B per token: what the selection needs about a token, in one place
     uint32_t rank;   // lexrank[id]: rank of the token's bytes in Python bytes order among all tokens
     uint32_t len;    // bytes
     unsigned long long hash; // yb_hash_bytes of its bytes
+    unsigned long long pre8; // its first eight bytes, big-endian, zero padded: integer order = bytes order as far as they decide
+    unsigned long long pad;
 };
+YB_HD unsigned long long yb_pre8(const uint8_t *p, uint32_t n) {
+    unsigned long long v = 0;
+    for (uint32_t i = 0; i < 8u; ++i) v = (v << 8) | (i < n ? (unsigned long long)p[i] : 0ull);
+    return v;
+}
 struct TokTable {
     uint8_t *pool;   // token bytes; every token starts at a multiple of 4
     uint32_t *off;
@@ -1396,49 +1310,83 @@ __device__ __forceinline__ int tok_cmp_concat(const TokTable &tt, uint32_t t, ui
     return (lt > lc) - (lt < lc);
 }
 
-// lexrank maintenance after a new token c = a + b was created (a, b, c in DevState): tokens above it move up by one, and
-// c's rank is the number of tokens below it.  The first block also writes c's bytes into the pool (the selection only
-// reserved the place: it works from hashes, see select_body).
+// Python bytes order between two concatenations a1 + b1 and a2 + b2 (two tokens the same batch has just created)
+__device__ __forceinline__ int tok_cmp_concat2(const TokTable &tt, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+    const uint8_t *pa1 = tt.pool + tt.off[a1], *pb1 = tt.pool + tt.off[b1], *pa2 = tt.pool + tt.off[a2], *pb2 = tt.pool + tt.off[b2];
+    const uint32_t la1 = tt.len[a1], l1 = la1 + tt.len[b1], la2 = tt.len[a2], l2 = la2 + tt.len[b2];
+    const uint32_t n = l1 < l2 ? l1 : l2;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int d = (int)(i < la1 ? pa1[i] : pb1[i - la1]) - (int)(i < la2 ? pa2[i] : pb2[i - la2]);
+        if (d) return d;
+    }
+    return (l1 > l2) - (l1 < l2);
+}
+
+// lexrank maintenance after the last selection created new tokens c_k = a_k + b_k (the batch in DevState; a_k, b_k are older
+// tokens, their bytes are in the pool): a token moves up by one for every new token below it, and a new token's rank is the
+// number of tokens below it.  The first block also writes the new tokens' bytes into the pool (the selection only reserved
+// the place: it works from hashes, see select_body).
 struct RankParams {
     TokTable tt;
     DevState *st;
 };
 
 __device__ __forceinline__ void rank_update_block(const RankParams &P, uint32_t block) {
-    __shared__ uint32_t s_less;
+    __shared__ uint32_t s_less[KMAX];
+    __shared__ BatchMerge s_m[KMAX];
     DevState *st = P.st;
     if (st->done | st->halt) return;
-    if (!st->c_is_new) return;
-    const uint32_t n = st->n_tokens, c = st->c, a = st->a, b = st->b;
-    if (block * BLOCK >= n) return;
-    if (threadIdx.x == 0) s_less = 0;
+    const uint32_t n = st->n_tokens, nb = min(st->n_batch, (uint32_t)KMAX);
+    if (threadIdx.x < (uint32_t)KMAX) {
+        s_less[threadIdx.x] = 0;
+        s_m[threadIdx.x] = threadIdx.x < nb ? st->batch[threadIdx.x] : BatchMerge{0u, 0u, 0u, 0u};
+    }
     __syncthreads();
-    if (block == 0) { // c's bytes, four at a time (the pool is 4-byte granular), written through
-        const uint8_t *pa = P.tt.pool + P.tt.off[a], *pb = P.tt.pool + P.tt.off[b];
-        const uint32_t la = P.tt.len[a], lc = la + P.tt.len[b];
-        uint32_t *dst = reinterpret_cast<uint32_t *>(P.tt.pool + P.tt.off[c]);
-        for (uint32_t w = threadIdx.x; w * 4u < lc; w += BLOCK) {
-            uint32_t v = 0;
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const uint32_t i = w * 4u + k;
-                if (i < lc) v |= (uint32_t)(i < la ? pa[i] : pb[i - la]) << (8u * k);
+    uint32_t n_new = 0;
+    for (uint32_t k = 0; k < nb; ++k) n_new += s_m[k].is_new;
+    if (n_new == 0) return;
+    const uint32_t n_old = n - n_new; // (new ids are the last ones: n_old .. n - 1 in batch order)
+    if (block * BLOCK >= n_old) return;
+    if (block == 0) {
+        for (uint32_t k = 0; k < nb; ++k) { // the new tokens' bytes, four at a time (the pool is 4-byte granular), written through
+            if (!s_m[k].is_new) continue;
+            const uint32_t a = s_m[k].a, b = s_m[k].b, c = s_m[k].c;
+            const uint8_t *pa = P.tt.pool + P.tt.off[a], *pb = P.tt.pool + P.tt.off[b];
+            const uint32_t la = P.tt.len[a], lc = la + P.tt.len[b];
+            uint32_t *dst = reinterpret_cast<uint32_t *>(P.tt.pool + P.tt.off[c]);
+            for (uint32_t w = threadIdx.x; w * 4u < lc; w += BLOCK) {
+                uint32_t v = 0;
+                for (uint32_t q = 0; q < 4u; ++q) {
+                    const uint32_t i = w * 4u + q;
+                    if (i < lc) v |= (uint32_t)(i < la ? pa[i] : pb[i - la]) << (8u * q);
+                }
+                st_coherent(&dst[w], v);
             }
-            st_coherent(&dst[w], v);
+        }
+        if (threadIdx.x < nb && s_m[threadIdx.x].is_new) { // new tokens among themselves
+            const uint32_t k = threadIdx.x;
+            uint32_t below = 0;
+            for (uint32_t k2 = 0; k2 < nb; ++k2)
+                if (k2 != k && s_m[k2].is_new && tok_cmp_concat2(P.tt, s_m[k2].a, s_m[k2].b, s_m[k].a, s_m[k].b) < 0) ++below;
+            if (below) atomicAdd(&s_less[k], below);
         }
     }
     const uint32_t t = block * BLOCK + threadIdx.x;
-    int less = 0;
-    if (t < n && t != c) {
-        const int cmp = tok_cmp_concat(P.tt, t, a, b);
-        if (cmp > 0)
-            st_coherent(&P.tt.rec[t].rank, P.tt.rec[t].rank + 1u); // (read by the selection of the same launch in the fused form)
-        else
-            less = 1;
+    uint32_t up = 0, lessbits = 0;
+    if (t < n_old) {
+        for (uint32_t k = 0; k < nb; ++k) {
+            if (!s_m[k].is_new) continue;
+            if (tok_cmp_concat(P.tt, t, s_m[k].a, s_m[k].b) > 0) ++up; else lessbits |= 1u << k;
+        }
+        if (up) st_coherent(&P.tt.rec[t].rank, P.tt.rec[t].rank + up); // (read by the selection of the same launch in the fused form)
     }
-    unsigned long long m = __ballot(less);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_less, (uint32_t)__popcll(m));
+    for (uint32_t k = 0; k < nb; ++k) {
+        if (!s_m[k].is_new) continue; // uniform
+        const unsigned long long m = __ballot((lessbits >> k) & 1u);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_less[k], (uint32_t)__popcll(m));
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && s_less) atomicAdd(&P.tt.rec[c].rank, s_less);
+    if (threadIdx.x < nb && s_m[threadIdx.x].is_new && s_less[threadIdx.x]) atomicAdd(&P.tt.rec[s_m[threadIdx.x].c].rank, s_less[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_rank_update(RankParams P) { rank_update_block(P, blockIdx.x); }
@@ -1496,212 +1444,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig(SigParams P) {
     }
 }
 
-// ---------------------------------------------------------------- split form, pass 2: balanced rewrite of the listed tiles
-struct SlowParams {
-    ApplyParams A;
-    const uint2 *work;
-    const uint32_t *work_cnt;
-    uint32_t n_lists; // grid of k_scan
-    uint32_t seg;
-    const uint2 *dense; // != NULL: items are dense[0 .. st->work_total) (sparse merges); falls back to the lists on overflow
-    uint32_t dense_cap;
-};
-constexpr int MAX_LISTS = 2048;
-
-template <bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void k_slow(SlowParams S) {
-    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    __shared__ uint32_t s_keys[AGG_N];
-    __shared__ AggV s_vals[AGG_N];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
-    __shared__ unsigned long long s_cnt[2];
-    __shared__ uint32_t s_pref[MAX_LISTS + 1];
-    __shared__ uint32_t s_wsum[WPB];
-
-    const ApplyParams &P = S.A;
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t total;
-    const bool dense = S.dense != nullptr && st->work_total <= S.dense_cap; // uniform over the grid
-    if (dense) {
-        total = st->work_total;
-        if (blockIdx.x * WPB >= total) return; // usually: nothing, or a handful of tiles
-    } else {
-    // exclusive prefix over the per-workgroup list lengths (every workgroup computes the same small scan)
-    constexpr int PER = MAX_LISTS / BLOCK;
-    uint32_t v[PER], tsum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const uint32_t i = threadIdx.x * PER + k;
-        v[k] = i < S.n_lists ? S.work_cnt[i] : 0u;
-        tsum += v[k];
-    }
-    uint32_t inc = tsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-    }
-    if (lane == 63) s_wsum[wib] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wib; ++w) woff += s_wsum[w];
-    uint32_t run = woff + inc - tsum;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        s_pref[threadIdx.x * PER + k] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == BLOCK - 1) s_pref[MAX_LISTS] = run;
-    __syncthreads();
-    total = s_pref[MAX_LISTS];
-    if (blockIdx.x * WPB >= total) return; // nothing for this workgroup (uniform)
-    }
-
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    C.mk = yb_memkey(C.a, C.b);
-    C.self = yb_pairkey(C.a, C.b);
-    agg_init(C.agg);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    WaveLds &W = s_w[wib];
-    wave_lds_init(W, lane);
-    __syncthreads();
-    unsigned long long wave_sites = 0, wave_freed = 0;
-    const uint32_t n_waves = gridDim.x * WPB;
-    // item g -> (tile, len): find the list that holds it (last l with s_pref[l] <= g)
-    auto fetch = [&](uint32_t g) -> uint2 {
-        if (dense) return S.dense[g];
-        uint32_t lo = 0, hi = S.n_lists;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= g) lo = mid; else hi = mid;
-        }
-        return S.work[(size_t)lo * S.seg + (g - s_pref[lo])];
-    };
-    uint32_t g = blockIdx.x * WPB + wib;
-    uint2 item = make_uint2(0u, 0u);
-    if (g < total) item = fetch(g); // (a wave past the end must not index the worklist at all)
-    TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
-    while (g < total) { // the next item's descriptor and data are in flight while this one is rewritten
-        const uint32_t tile = item.x, len = item.y;
-        const TileRegs r = nxt;
-        g += n_waves;
-        if (g < total) {
-            item = fetch(g);
-            nxt = load_tile(P.tiles, item.x, item.y, lane);
-        }
-        const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-        const uint32_t na = next_lane(r.va.x, b0);
-        const uint32_t nb = next_lane(r.vb.x, PADPAD);
-        slow_tile<WEIGHTED, AggV>(C, W, tile, len, r, na, nb, wave_sites, wave_freed);
-    }
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
-}
-
-// ---------------------------------------------------------------- split form fused again on top of the skip index
-// k_apply_skip = k_scan_skip + the rewrite, in one launch: once the signatures have removed most tiles from the scan,
-// a second kernel (worklist, prefix, re-read of the tiles) costs more than it saves.  Stragglers are handled by
-// dynamic scheduling instead: workgroups draw chunks of SCAN_CHUNK consecutive tiles from 8 sharded queue heads in
-// DevState (reset by k_select), and inside a chunk the waves draw candidate tiles from an LDS counter.
-struct ApplySkipParams {
-    ApplyParams A;
-    uint32_t n_chunks;
-    unsigned long long *blk_read; // [gridDim.x] candidate tiles read (statistics)
-};
-
-template <bool WEIGHTED>
-__global__ __launch_bounds__(BLOCK) void k_apply_skip(ApplySkipParams Q) {
-    using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    __shared__ uint32_t s_keys[AGG_N];
-    __shared__ AggV s_vals[AGG_N];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
-    __shared__ unsigned long long s_cnt[2];
-    __shared__ uint2 s_list[SCAN_CHUNK];
-    __shared__ uint32_t s_n, s_take, s_chunk;
-
-    const ApplyParams &P = Q.A;
-    DevState *st = P.st;
-    if (st->done | st->halt) return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    C.mk = yb_memkey(C.a, C.b);
-    C.self = yb_pairkey(C.a, C.b);
-    const uint32_t mk = C.mk;
-    const SigProbe probe = sig_probe(P.sig, P.sig_stride, C.self);
-    agg_init(C.agg);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    WaveLds &W = s_w[wib];
-    wave_lds_init(W, lane);
-    const uint32_t nq = min(8u, gridDim.x);  // queue shards in use (every shard needs at least one workgroup)
-    const uint32_t q = blockIdx.x % nq;      // this workgroup's shard: chunks q, q + nq, q + 2 nq, ...
-    if (threadIdx.x == 0) {
-        s_n = 0;
-        s_take = 0;
-        s_chunk = atomicAdd(&st->chunk_next[q], 1u) * nq + q;
-    }
-    __syncthreads();
-
-    unsigned long long wave_sites = 0, wave_freed = 0, n_read = 0;
-    while (true) {
-        const uint32_t ch = s_chunk; // uniform
-        if (ch >= Q.n_chunks) break;
-        // ---- one thread per tile: signature test (16 B per tile)
-        const uint32_t t = ch * SCAN_CHUNK + threadIdx.x;
-        uint32_t len = 0;
-        bool maybe = false;
-        if (t < P.n_tiles) {
-            len = P.tile_len[t];
-            maybe = len != 0 && probe.maybe(t);
-        }
-        const unsigned long long m = __ballot(maybe);
-        uint32_t base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (maybe) s_list[base + bits_below_lane(m)] = make_uint2(t, len);
-        __syncthreads();
-        const uint32_t n = s_n;
-        n_read += n;
-        if (threadIdx.x == 0) s_chunk = atomicAdd(&st->chunk_next[q], 1u) * nq + q; // next chunk id arrives meanwhile
-        // ---- candidates: waves draw them one at a time; matched tiles are rewritten on the spot
-        uint32_t j = 0;
-        if (lane == 0) j = atomicAdd(&s_take, 1u);
-        j = __builtin_amdgcn_readfirstlane(j);
-        uint2 item = j < n ? s_list[j] : make_uint2(0u, 0u);
-        TileRegs nxt = load_tile(P.tiles, item.x, item.y, lane);
-        while (j < n) {
-            const uint2 cur = item;
-            const TileRegs r = nxt;
-            if (lane == 0) j = atomicAdd(&s_take, 1u);
-            j = __builtin_amdgcn_readfirstlane(j);
-            if (j < n) {
-                item = s_list[j];
-                nxt = load_tile(P.tiles, item.x, item.y, lane);
-            }
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_n = 0;
-            s_take = 0;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
-#ifdef YB_PROFILE_SLOW
-    if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
-#endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
-}
-
 // ================================================================ long words (> LMAX-1 tokens): one workgroup per word
 struct LongParams {
     uint16_t *tok;
@@ -1752,8 +1494,11 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     __shared__ uint32_t s_hit[BLOCK];
     DevState *st = P.st;
     if (st->done | st->halt) return;
-    const uint32_t a = st->a, b = st->b, c = st->c;
+    const uint32_t nbatch = min(st->n_batch, (uint32_t)KMAX);
+    for (uint32_t bk = 0; bk < nbatch; ++bk) { // the merges of the batch, in order (a workgroup owns its words)
+    const uint32_t a = st->batch[bk].a, b = st->batch[bk].b, c = st->batch[bk].c;
     const uint32_t self = yb_pairkey(a, b);
+    __syncthreads();
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     {
@@ -1841,6 +1586,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
         if (sites) atomicAdd(&st->sites, sites);
     }
     __syncthreads();
+    }
     }
 }
 
@@ -1953,6 +1699,7 @@ struct SelectParams {
     unsigned long long *blk_stats;      // per-workgroup counters of the last k_apply
     uint32_t n_blk;
     CandState *cs;                      // != NULL: the partials come from k_argmax_cand
+    uint32_t flat_single;               // 1: flat layout on one GPU -- a merge's count is the number of its sites (a != b): per-merge site log of a batch
 };
 
 // Adds the per-workgroup counters of the last apply pass to DevState and clears them (one workgroup).
@@ -2018,18 +1765,19 @@ __device__ __forceinline__ void ld_rec_coherent(const TokRec *r, uint32_t &rank,
     rank = (uint32_t)a;
     len = (uint32_t)(a >> 32);
 }
+template <int NF = 4> // entries in flight per thread
 __device__ __forceinline__ BestEx cand_list_best(const PairTable &t, const TokRec *rec, uint32_t n, uint32_t first, uint32_t step) {
     BestEx best = best_ex_none();
-    for (uint32_t i0 = first; i0 < n; i0 += 4u * step) {
-        unsigned long long e[4], cn[4], hx[4], hy[4];
-        uint32_t rl[4], rr[4], lx[4], ly[4];
+    for (uint32_t i0 = first; i0 < n; i0 += (uint32_t)NF * step) {
+        unsigned long long e[NF], cn[NF], hx[NF], hy[NF];
+        uint32_t rl[NF], rr[NF], lx[NF], ly[NF];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NF; ++k) {
             const uint32_t i = i0 + (uint32_t)k * step;
             e[k] = i < n ? ld_coherent(&t.cand_list[i]) : ~0ull;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NF; ++k) {
             cn[k] = 0ull;
             if (i0 + (uint32_t)k * step < n) {
                 const uint32_t key = (uint32_t)(e[k] >> 32);
@@ -2039,7 +1787,7 @@ __device__ __forceinline__ BestEx cand_list_best(const PairTable &t, const TokRe
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NF; ++k) {
             if ((long long)cn[k] <= 0) continue;
             const Best b{cn[k], (rl[k] << 16) | rr[k], (uint32_t)(e[k] >> 32), (uint32_t)e[k], 0u};
             if (best_gt(b, best.b)) best = BestEx{b, hx[k], hy[k], lx[k], ly[k], 1u};
@@ -2048,37 +1796,85 @@ __device__ __forceinline__ BestEx cand_list_best(const PairTable &t, const TokRe
     return best;
 }
 
-// One workgroup: commits a pending halt, folds the apply pass's counters, reduces the argmax partials, applies the
-// stop rules and creates the merged token.  Runs as k_select, as the tail of k_argmax_cand in its last workgroup, or as the
-// tail of the fused per-merge launch.  This is a chain of dependent memory round trips on the critical path of every
-// merge, so it is kept short:
-//   - thread 0 works on a register copy of DevState (one load of the whole struct, one store at the end), and everything
-//     that does not depend on the winner (DevState, block counters, partials) is requested in the same round;
-//   - the merged token is created from the two tokens' records: its hash follows from theirs (yb_hash_concat), one probe of
+// ---------------------------------------------------------------- batches of merges (sparse phase)
+// Sequential BPE (trainer.py:241-300) selects merge t+1 from the counts merge t left behind.  One look at the pair table
+// can nevertheless fix SEVERAL consecutive merges, whenever it proves that applying the first ones cannot change which pair
+// comes next.  Walk the pairs in selection order -- (count, bytes(left), bytes(right)) descending -- and accept candidate
+// j = (p, q) with count n_j after the accepted merges i = (a_i, b_i) -> c_i iff
+//   (1) q != a_i and p != b_i for every i: merge i lowers only the counts of (x, a_i), (b_i, y) and (a_i, b_i) itself
+//       (trainer.py:264-273), so j's count is still n_j when its turn comes;
+//   (2) no pair that merge i CREATES can come before j.  Such a pair contains c_i -- (x, c_i), (c_i, y), (c_i, c_i') -- and
+//       its count is at most what the pair it grew out of had: count(x, a_i), count(b_i, y), count(b_i, a_i').  A pair with a
+//       larger count than n_j would have been walked before j and ended the batch by rule (1), so only pairs that TIE with j
+//       matter: for every pair e = (l, r) with count == n_j that is not in the batch and has r == a_i or l == b_i, each pair it
+//       can turn into must sort below j by bytes.  Old tokens compare by lexrank; a new token c_i = a_i + b_i by its first
+//       eight bytes and its length (TokRec::pre8), and "cannot tell" counts as "comes before j";
+//   (3) c_i is a NEW token (an existing token's pairs already have counts) and a_i != b_i (a run a a a leaves (c, a) pairs
+//       whose count is bounded only by the merged pair's own); such a merge may close a batch but not sit inside one;
+// and stop at the first candidate that fails.  Every pair with count >= T is on the candidate list, so all of this is
+// decided from what the selection reads anyway.  tools/batch_sim.cpp replays the rule against sequential BPE on the CPU.
+constexpr int WIN = 128; // window of the walk: the candidate-list entries with the highest counts (whole count levels)
+struct WinEnt {
+    unsigned long long cnt;
+    uint32_t key, slot, rk, lx, ly, pad; // lx, ly: byte lengths of the two tokens
+    unsigned long long hx, hy, px, py;   // their hashes and 8-byte prefixes
+};
+struct AccEnt { // an accepted merge: what the tie rule needs about it
+    uint32_t a, b, lc, win; // lc: byte length of the merged token, win: its window entry
+    unsigned long long pc;  // 8-byte prefix of the merged token
+};
+// first eight bytes of x + y (big-endian, zero padded), from the parts' prefixes
+__device__ __forceinline__ unsigned long long pre8_concat(unsigned long long px, uint32_t lx, unsigned long long py) {
+    return lx >= 8u ? px : (px | (py >> (8u * lx)));
+}
+// Python bytes order from prefixes and lengths: -1 / 0 / +1, or 2 when the first eight bytes do not decide
+__device__ __forceinline__ int cmp_pre8(unsigned long long px, uint32_t lx, unsigned long long py, uint32_t ly) {
+    if (px != py) return px < py ? -1 : 1; // (a zero pad byte sorts like a string that has ended: a proper prefix is smaller)
+    if (lx <= 8u && ly <= 8u) return lx < ly ? -1 : lx > ly ? 1 : 0;
+    return 2;
+}
+
+// One workgroup: commits a pending halt, folds the apply pass's counters, finds the next merge (EVAL: on the candidate list,
+// else among the argmax partials), applies the stop rules and creates the merged token; EVAL with kmax > 1: extends the
+// selection to a batch (see above).  Runs as k_select, as the tail of k_argmax_cand in its last workgroup, or as the tail of
+// the fused per-merge launch.  This is a chain of dependent memory round trips on the critical path of every launch, so it
+// is kept short:
+//   - thread 0 keeps the DevState fields it needs in registers, and everything that does not depend on the winner (DevState,
+//     block counters, partials, the list) is requested in the same round;
+//   - a merged token is created from the two tokens' records: its hash follows from theirs (yb_hash_concat), one probe of
 //     the byte-string set says whether those bytes are already a token (trainer.py:298), and its bytes are written by the
 //     NEXT launch (rank_update_block) -- the winner's bytes are never read here unless hash and length match an entry.
-// `mine`: this thread's candidate from the caller (the fused form evaluates the candidate list right here).
+// `mine`: this thread's candidate from the caller.
 template <bool EVAL>
 __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) {
     __shared__ Best s_b[WPB];
     __shared__ uint32_t s_flag, s_slot, s_eq, s_lx, s_ly, s_have;
     __shared__ unsigned long long s_fold[2], s_hx, s_hy, s_ent;
+    // batch selection
+    __shared__ WinEnt s_win[EVAL ? WIN : 1];
+    __shared__ AccEnt s_acc[KMAX];
+    __shared__ unsigned long long s_lvl[WPB], s_pH[KMAX];
+    __shared__ uint32_t s_hset[EVAL ? 2 * WIN : 1];
+    __shared__ uint32_t s_nwin, s_ext, s_stop, s_nacc, s_cpos, s_pslot[KMAX], s_phit[KMAX], s_pL[KMAX];
+    __shared__ uint32_t s_it, s_ntok, s_pool;
+    __shared__ unsigned long long s_px, s_py;
     DevState *st = P.st;
     const int tid = threadIdx.x;
     YB_SEL_STAMP(1);
     // ---- round trip 1: everything that depends on nothing.  EVAL (fused form): the first 4 x BLOCK entries of the
     // candidate list and its length (the list's storage exists up to CAND_CAP; what lies past n is ignored) ...
-    unsigned long long e[4];
-    uint32_t n_list = 0;
+    unsigned long long e[4] = {0ull, 0ull, 0ull, 0ull}, cn[4] = {0ull, 0ull, 0ull, 0ull};
+    uint32_t n_list = 0, kmax = 1;
     if constexpr (EVAL) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
         n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
+        kmax = min(st->kmax, (uint32_t)KMAX);
     }
     // ... the fields of DevState the selection needs (thread 0 keeps them in registers and writes back what it changes,
     // field by field: a working copy of the whole struct was 36 registers in every lane, and in LDS it made thread 0's
     // serial part a chain of LDS round trips) ...
-    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0;
+    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0, d_prev_batch = 0;
     unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0;
     unsigned long long candT = 0;
     uint32_t cand_over = 0, cand_n = 0;
@@ -2092,6 +1888,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         d_min_freq = st->min_freq;
         d_live_slots = st->live_slots;
         d_tokens_now = st->tokens_now;
+        d_prev_batch = st->n_batch;
         // fields other workgroups of this launch may have moved (atomics): read them past the caches
         d_halt_req = ld_coherent(&st->halt_req);
         d_table_entries = ld_coherent(&st->table_entries);
@@ -2105,6 +1902,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         s_fold[1] = 0;
         s_flag = 0;
         s_have = 0;
+        s_nwin = 0;
+        s_ext = 0;
+        s_nacc = 0;
     }
     // ... and the counters of the last apply pass (one slot per workgroup), summed and cleared further down
     unsigned long long vx[4], vy[4];
@@ -2114,49 +1914,18 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         vx[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i]) : 0ull;
         vy[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i + 1]) : 0ull;
     }
-    // ---- round trip 2 (EVAL): the counts of this thread's entries (the slot rides in the list) -- requested before the
-    // counters are looked at.  Round trip 3: ranks, lengths and hashes (a token's record is 16 B) only for the entries
-    // that hold the maximum count: the ranks only break ties, and every scattered load of this ONE workgroup costs a cycle
-    // of its CU's address path (4 x BLOCK entries x 5 loads were 2 us).
+    // ---- round trip 2 (EVAL): the counts of this thread's entries (the slot rides in the list).  Round trip 3: ranks, lengths, hashes and prefixes (a token's record is 32 B) only for the
+    // entries of the window (kmax > 1: the highest count levels, at most WIN entries) or for those that hold the maximum
+    // count: every scattered load of this ONE workgroup costs a cycle of its CU's address path.
+    uint32_t n_win = 0, mypos = 0xffffffffu; // window entries; this thread's entry (tid < n_win) in selection order
     if constexpr (EVAL) {
-        __shared__ unsigned long long s_max[WPB];
-        unsigned long long cn[4], cmax = 0ull;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             cn[k] = 0ull;
             if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(pt_count_ptr(P.table, e[k]));
         }
-        if (n_list != 0xdeadbeefu) YB_SEL_STAMP(9); // (profile build: list length + entries have arrived, counts requested)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((long long)cn[k] <= 0) cn[k] = 0ull;
-            cmax = cn[k] > cmax ? cn[k] : cmax;
-        }
-        if (cmax != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(10); // (counts have arrived)
-        cmax = best_wave_reduce(Best{cmax, 0u, 0u, 0u, 0u}).cnt;
-        if ((tid & 63) == 0) s_max[tid >> 6] = cmax;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < WPB; ++w) cmax = s_max[w] > cmax ? s_max[w] : cmax;
-        if (cmax) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (cn[k] != cmax) continue;
-                const uint32_t key = (uint32_t)(e[k] >> 32);
-                uint32_t rl, rr, lx, ly;
-                unsigned long long hx, hy;
-                ld_rec_coherent(&P.tt.rec[key >> 16], rl, lx, hx);
-                ld_rec_coherent(&P.tt.rec[key & 0xffffu], rr, ly, hy);
-                const Best b{cn[k], (rl << 16) | rr, key, (uint32_t)e[k], 0u};
-                if (best_gt(b, mine.b)) mine = BestEx{b, hx, hy, lx, ly, 1u};
-            }
-        }
-        if (mine.b.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11); // (records of the tied entries have arrived)
-        if (n_list > 4u * BLOCK) { // a long list (the host keeps it shorter than this): the rest, four per thread at a time
-            const BestEx more = cand_list_best(P.table, P.tt.rec, n_list, 4u * BLOCK + tid, BLOCK);
-            if (best_gt(more.b, mine.b)) mine = more;
-        }
     }
+    // (the counters are summed while the counts are on their way: their registers are free for what follows)
     unsigned long long fa = 0, ff = 0;
     {
         unsigned long long *bs = P.blk_stats;
@@ -2170,7 +1939,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
                 bs[2 * i + 1] = 0ull;
             }
         }
-        for (uint32_t i = 4 * BLOCK + tid; i < P.n_blk; i += BLOCK) { // (grids beyond 1,024 workgroups: the dense phase)
+        for (uint32_t i = 4 * BLOCK + tid; i < P.n_blk; i += BLOCK) { // (grids beyond 1,024 workgroups: the streaming phase)
             const unsigned long long x = ld_coherent(&bs[2 * i]), y = ld_coherent(&bs[2 * i + 1]);
             fa += x;
             ff += y;
@@ -2180,10 +1949,141 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             }
         }
     }
+    if constexpr (EVAL) {
+        unsigned long long cmax = 0ull;
+        if (n_list != 0xdeadbeefu) YB_SEL_STAMP(9); // (profile build: list length + entries have arrived, counts requested)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((long long)cn[k] <= 0) cn[k] = 0ull;
+            cmax = cn[k] > cmax ? cn[k] : cmax;
+        }
+        if (cmax != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(10); // (counts have arrived)
+        // The window: the pairs on the highest count levels, whole levels, at most WIN pairs.  A pair can be on the list more
+        // than once (cand_note) and how often differs from replica to replica (multi-GPU), so the window is built from DISTINCT
+        // pairs -- a small hash set in LDS keeps the repeats out -- and every decision below depends on the pairs and their counts
+        // only: all ranks walk the same window and select the same batch.  Entries past the first 4 x BLOCK (a long list: rare,
+        // the host rebuilds it before) are streamed from memory in every step instead of sitting in registers.
+        unsigned long long L = 0ull, bound = ~0ull; // levels below `bound` are still to be visited
+        uint32_t total = 0;
+        bool win_ok = false;
+        const uint32_t max_levels = kmax > 1u ? kmax : 1u;
+        constexpr uint32_t HSET = 2 * WIN;
+        for (uint32_t hidx = tid; hidx < HSET; hidx += BLOCK) s_hset[hidx] = EMPTY;
+        for (uint32_t lv = 0; lv < max_levels; ++lv) {
+            unsigned long long m = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m = (cn[k] < bound && cn[k] > m) ? cn[k] : m;
+            for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) { // (long list)
+                const long long c = (long long)ld_coherent(pt_count_ptr(P.table, ld_coherent(&P.table.cand_list[ti])));
+                if (c > 0 && (unsigned long long)c < bound && (unsigned long long)c > m) m = (unsigned long long)c;
+            }
+            m = best_wave_reduce(Best{m, 0u, 0u, 0u, 0u}).cnt;
+            __syncthreads(); // (s_lvl of the last round is read)
+            if ((tid & 63) == 0) s_lvl[tid >> 6] = m;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) m = s_lvl[w] > m ? s_lvl[w] : m;
+            if (m == 0ull) break; // nothing below
+            if (lv == 0) cmax = m;
+            if (kmax <= 1u) break; // (one merge per selection: no window)
+            // this level's pairs -> window (first listing of a pair only)
+            auto put = [&](unsigned long long ent, unsigned long long c) {
+                const uint32_t key = (uint32_t)(ent >> 32);
+                uint32_t h = hash32(key) & (HSET - 1u);
+                for (uint32_t probe = 0; probe < HSET; ++probe) {
+                    const uint32_t was = atomicCAS(&s_hset[h], EMPTY, key);
+                    if (was == key) return; // listed twice
+                    if (was == EMPTY) {
+                        const uint32_t idx = atomicAdd(&s_nwin, 1u);
+                        if (idx < (uint32_t)WIN) {
+                            s_win[idx].cnt = c;
+                            s_win[idx].key = key;
+                            s_win[idx].slot = (uint32_t)ent;
+                        }
+                        return;
+                    }
+                    h = (h + 1u) & (HSET - 1u);
+                }
+                s_nwin = WIN + 1u; // (the set is full: more distinct pairs than a window holds)
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cn[k] == m) put(e[k], m);
+            for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) {
+                const unsigned long long ent = ld_coherent(&P.table.cand_list[ti]);
+                if (ld_coherent(pt_count_ptr(P.table, ent)) == m) put(ent, m);
+            }
+            __syncthreads();
+            const uint32_t now = s_nwin;
+            if (now > (uint32_t)WIN) break; // (this level does not fit: the window ends above it)
+            total = now;
+            L = m;
+            win_ok = true;
+            bound = m;
+            if (total >= 4u * kmax) break; // plenty
+        }
+        (void)L;
+        if (win_ok) {
+            // ONE entry per thread fetches its two token records (a round trip for all)
+            if ((uint32_t)tid < total) {
+                const uint32_t key = s_win[tid].key;
+                const unsigned long long *qx = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key >> 16]);
+                const unsigned long long *qy = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key & 0xffffu]);
+                const unsigned long long ax = ld_coherent(qx), hx = ld_coherent(qx + 1), px = ld_coherent(qx + 2);
+                const unsigned long long ay = ld_coherent(qy), hy = ld_coherent(qy + 1), py = ld_coherent(qy + 2);
+                s_win[tid].rk = ((uint32_t)ax << 16) | ((uint32_t)ay & 0xffffu);
+                s_win[tid].lx = (uint32_t)(ax >> 32);
+                s_win[tid].ly = (uint32_t)(ay >> 32);
+                s_win[tid].hx = hx;
+                s_win[tid].hy = hy;
+                s_win[tid].px = px;
+                s_win[tid].py = py;
+            }
+            __syncthreads();
+            n_win = total;
+            // selection order by counting: an entry's position is the number of entries in front of it
+            if ((uint32_t)tid < n_win) {
+                const unsigned long long c0 = s_win[tid].cnt;
+                const uint32_t r0 = s_win[tid].rk;
+                uint32_t pos = 0;
+                for (uint32_t u = 0; u < n_win; ++u) {
+                    const unsigned long long cu = s_win[u].cnt;
+                    const uint32_t ru = s_win[u].rk;
+                    pos += (cu > c0) || (cu == c0 && (ru > r0 || (ru == r0 && u < (uint32_t)tid)));
+                }
+                mypos = pos;
+                if (pos == 0) {
+                    const WinEnt w = s_win[tid];
+                    mine = BestEx{Best{w.cnt, w.rk, w.key, w.slot, 0u}, w.hx, w.hy, w.lx, w.ly, 1u};
+                    s_px = w.px;
+                    s_py = w.py;
+                }
+            }
+        } else { // (cmax is the maximum over the whole list: level 0 of the loop above)
+            if (cmax) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cn[k] != cmax) continue;
+                    const uint32_t key = (uint32_t)(e[k] >> 32);
+                    uint32_t rl, rr, lx, ly;
+                    unsigned long long hx, hy;
+                    ld_rec_coherent(&P.tt.rec[key >> 16], rl, lx, hx);
+                    ld_rec_coherent(&P.tt.rec[key & 0xffffu], rr, ly, hy);
+                    const Best b{cn[k], (rl << 16) | rr, key, (uint32_t)e[k], 0u};
+                    if (best_gt(b, mine.b)) mine = BestEx{b, hx, hy, lx, ly, 1u};
+                }
+            }
+            if (n_list > 4u * BLOCK) { // a long list (the host keeps it shorter than this): the rest, four per thread at a time
+                const BestEx more = cand_list_best<1>(P.table, P.tt.rec, n_list, 4u * BLOCK + tid, BLOCK); // (rare: one entry at a time keeps the registers of the common path)
+                if (best_gt(more.b, mine.b)) mine = more;
+            }
+        }
+        if (mine.b.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11); // (records have arrived)
+    }
     Best best = mine.b;
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
-        const Best e = best_load_coherent(&P.partials[i]);
-        if (best_gt(e, best)) best = e;
+        const Best pe = best_load_coherent(&P.partials[i]);
+        if (best_gt(pe, best)) best = pe;
     }
     fa = wave_sum_u64(fa);
     ff = wave_sum_u64(ff);
@@ -2206,7 +2106,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         }
         // Deterministic across ranks (all replicas hold the same keys): stop before the table gets crowded, so that
         // no replica can run out of probes on its own.
-        if (!P.table.dense && d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full
+        if (d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full
         d_sites += s_fold[0];
         d_live_slots -= s_fold[1];
         if (d_done | d_halt) {
@@ -2215,9 +2115,22 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             for (int w = 1; w < WPB; ++w)
                 if (best_gt(s_b[w], best)) best = s_b[w];
             s_b[0] = best;
-            // close the log entry of the previous iteration
+            // close the log entries of the batch that has just been applied: merges [it - pb, it).  Flat layout, a != b: a
+            // merge's sites are exactly its count, and only the last merge of a batch can have a == b -- it gets what is
+            // left.  (Pooled words / several ranks: counts are not resident sites; the whole batch is logged on its last merge.)
             const uint32_t it = d_iter;
-            if (it > P.rec_base && d_sites) P.rec_sites[it - 1 - P.rec_base] = d_sites; // (0: already closed, this is a re-run)
+            if (it > P.rec_base && d_sites) { // (0: already closed, this is a re-run)
+                const uint32_t pb = min(max(d_prev_batch, 1u), it - P.rec_base);
+                unsigned long long others = 0;
+                if (P.flat_single)
+                    for (uint32_t m = it - pb; m + 1 < it; ++m) others += P.rec_count[m - P.rec_base];
+                if (others <= d_sites && P.flat_single) {
+                    for (uint32_t m = it - pb; m + 1 < it; ++m) P.rec_sites[m - P.rec_base] = P.rec_count[m - P.rec_base];
+                    P.rec_sites[it - 1 - P.rec_base] = d_sites - others;
+                } else {
+                    P.rec_sites[it - 1 - P.rec_base] = d_sites;
+                }
+            }
             d_tokens_now -= d_sites;
             d_sites = 0;
             if (P.cs && it < d_num_merges && (best.cnt < candT || cand_over)) {
@@ -2237,8 +2150,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         st->live_slots = d_live_slots;
         st->tokens_now = d_tokens_now;
         st->cand_n = cand_n;
-        st->work_total = 0u;
-        for (int q = 0; q < 8; ++q) st->chunk_next[q] = 0u;
+        if (s_flag) st->n_batch = 0u;
     }
     __syncthreads();
     if (s_flag) return;
@@ -2246,7 +2158,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     const Best win = s_b[0];
     const uint32_t x = win.key >> 16, y = win.key & 0xffffu;
     // the two tokens' lengths and hashes: in the registers of the thread whose candidate won, or one more round trip
-    if (mine.have && mine.b.key == win.key && mine.b.cnt == win.cnt) { // (keys are unique on the list: one thread at most)
+    if (EVAL && n_win && mine.have && mine.b.key == win.key && mine.b.cnt == win.cnt) { // (the window's first entry: one thread; it has left the prefixes too)
         s_hx = mine.hx;
         s_hy = mine.hy;
         s_lx = mine.lx;
@@ -2254,9 +2166,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         s_have = 1;
     }
     __syncthreads();
-    if (!s_have && tid < 2) { // (winner came from another workgroup's partial, or from a scan of the table)
+    if (!s_have && tid < 2) { // (no window: the winner's two records, prefixes included -- one more round trip)
         const TokRec r = P.tt.rec[tid ? y : x];
-        if (tid) { s_hy = r.hash; s_ly = r.len; } else { s_hx = r.hash; s_lx = r.len; }
+        if (tid) { s_hy = r.hash; s_ly = r.len; s_py = r.pre8; } else { s_hx = r.hash; s_lx = r.len; s_px = r.pre8; }
     }
     __syncthreads();
     YB_SEL_STAMP(4);
@@ -2266,13 +2178,13 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     // holds another string is passed over without looking at that string
     if (tid == 0) {
         uint32_t slot = yb_vset_home(H, L) & P.tt.vset_mask;
-        unsigned long long e = P.tt.vset[slot];
-        while (e != VSET_EMPTY && (e >> 32) != (H >> 32)) {
+        unsigned long long ve = P.tt.vset[slot];
+        while (ve != VSET_EMPTY && (ve >> 32) != (H >> 32)) {
             slot = (slot + 1) & P.tt.vset_mask;
-            e = P.tt.vset[slot];
+            ve = P.tt.vset[slot];
         }
         s_slot = slot;
-        s_ent = e;
+        s_ent = ve;
     }
     __syncthreads();
     YB_SEL_STAMP(5);
@@ -2298,68 +2210,209 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         }
         if (tid == 0) { // next slot with the same 32 hash bits, or the empty slot that ends the run
             uint32_t slot = (s_slot + 1) & P.tt.vset_mask;
-            unsigned long long e = P.tt.vset[slot];
-            while (e != VSET_EMPTY && (e >> 32) != (H >> 32)) {
+            unsigned long long ve = P.tt.vset[slot];
+            while (ve != VSET_EMPTY && (ve >> 32) != (H >> 32)) {
                 slot = (slot + 1) & P.tt.vset_mask;
-                e = P.tt.vset[slot];
+                ve = P.tt.vset[slot];
             }
             s_slot = slot;
-            s_ent = e;
+            s_ent = ve;
         }
         __syncthreads();
     }
     YB_SEL_STAMP(6);
     if (tid == 0) {
-        uint32_t cid;
+        uint32_t cid = 0;
         uint32_t is_new = 0;
+        bool ok = true;
         if (found != EMPTY) {
             cid = found; // bytes already a token: no id is consumed (trainer.py:298-300)
         } else if (d_n_tokens >= YB_MAX_TOKENS) {
             st->halt = HALT_VOCAB_FULL;
-            return;
-        } else if (P.table.dense && d_n_tokens >= P.table.dense_v) {
-            st->halt = HALT_MATRIX_ROWS; // (the host adds rows ahead of time; this is the net under it)
-            return;
+            st->n_batch = 0u;
+            ok = false;
         } else if ((unsigned long long)pu + L + 4ull > P.tt.pool_cap) {
             st->halt = HALT_POOL_FULL;
-            return;
+            st->n_batch = 0u;
+            ok = false;
         } else {
             cid = d_n_tokens; // merged = p0 + p1 (trainer.py:251): place reserved, bytes written by the next launch
             P.tt.off[cid] = pu;
             P.tt.len[cid] = L;
-            P.tt.rec[cid] = TokRec{0u, L, H};
-            P.tt.vset[s_slot] = yb_vset_entry(cid, H);
-            st->pool_used = (pu + L + 3u) & ~3u;
-            st->n_tokens = cid + 1;
+            P.tt.rec[cid] = TokRec{0u, L, H, pre8_concat(s_px, s_lx, s_py), 0ull};
+            st_coherent(&P.tt.vset[s_slot], yb_vset_entry(cid, H)); // (the probes of the rest of the batch may pass this slot)
             is_new = 1;
         }
-        const uint32_t ri = d_iter - P.rec_base;
-        P.rec_left[ri] = x; // merges.append(best_pair) (trainer.py:296)
-        P.rec_right[ri] = y;
-        P.rec_merged[ri] = cid;
-        P.rec_count[ri] = win.cnt;
-        P.rec_live_slots[ri] = d_live_slots;
-        // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
-        // set it here once instead of letting every workgroup subtract its share from one hot address
-        if (P.table.dense) {
-            P.table.dense[tri_idx(win.key)] = 0ull;
-            // every adjacency this merge creates contains cid: its row can gain at most the merged count per pair
-            const unsigned long long rm = is_new ? 0ull : P.table.rowmax[cid];
-            P.table.rowmax[cid] = rm > ~0ull - win.cnt ? ~0ull : rm + win.cnt;
-        } else {
+        if (ok) {
+            const uint32_t ri = d_iter - P.rec_base;
+            P.rec_left[ri] = x; // merges.append(best_pair) (trainer.py:296)
+            P.rec_right[ri] = y;
+            P.rec_merged[ri] = cid;
+            P.rec_count[ri] = win.cnt;
+            P.rec_live_slots[ri] = d_live_slots;
+            // after this merge no (x,y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0:
+            // set it here once instead of letting every workgroup subtract its share from one hot address
             P.table.cnt[win.slot] = 0ull;
-        }
-        st->a = x;
-        st->b = y;
-        st->c = cid;
-        st->best_count = win.cnt;
-        st->c_is_new = is_new;
-        st->iter = d_iter + 1;
+            st->a = x;
+            st->b = y;
+            st->c = cid;
+            st->best_count = win.cnt;
+            st->c_is_new = is_new;
+            st->batch[0] = BatchMerge{x, y, cid, is_new};
+            st->n_batch = 1u;
+            st->iter = d_iter + 1;
+            st->pool_used = is_new ? ((pu + L + 3u) & ~3u) : pu;
+            st->n_tokens = d_n_tokens + is_new;
+            // may the batch go on?  (rule (3); the walk needs the window)
+            if (EVAL && is_new && x != y && n_win > 1u && kmax > 1u && d_iter + 1u < d_num_merges) {
+                s_ext = 1;
+                s_it = d_iter + 1u;
+                s_ntok = d_n_tokens + 1u;
+                s_pool = (pu + L + 3u) & ~3u;
+                s_acc[0] = AccEnt{x, y, L, 0u, pre8_concat(s_px, s_lx, s_py)};
+                s_pH[0] = H;
+                s_pL[0] = L;
+                s_pslot[0] = s_slot;
+                s_nacc = 1u;
+            }
 #ifdef YB_PROFILE_LAUNCH
-        g_launch_prof[(d_iter & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
+            g_launch_prof[(d_iter & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
 #endif
+        }
     }
     YB_SEL_STAMP(7);
+    if constexpr (EVAL) {
+        __syncthreads();
+        if (!s_ext) return;
+        // ---- the walk: candidates in selection order from position 1 on
+        const bool mine_in = (uint32_t)tid < n_win;
+        unsigned long long me_cnt = 0ull;
+        uint32_t me_key = 0u, me_rk = 0u;
+        if (mine_in) {
+            me_cnt = s_win[tid].cnt;
+            me_key = s_win[tid].key;
+            me_rk = s_win[tid].rk;
+        }
+        if (mine_in && mypos == 0u) s_acc[0].win = (uint32_t)tid;
+        const unsigned long long candT_all = P.cs->T, min_freq = st->min_freq; // (uniform loads)
+        const uint32_t num_merges = st->num_merges;
+        for (uint32_t pos = 1; pos < n_win; ++pos) {
+            __syncthreads(); // (s_acc / s_nacc of the last round are complete; s_stop was read)
+            const uint32_t nacc = s_nacc;
+            if (nacc >= kmax || s_it + (nacc - 1u) >= num_merges) break;
+            if (tid == 0) s_stop = 0;
+            if (mine_in && mypos == pos) s_cpos = (uint32_t)tid;
+            __syncthreads();
+            const uint32_t cpos = s_cpos;
+            struct { unsigned long long cnt, px, py; uint32_t key, rk, lx, ly; } cj; // (broadcast reads)
+            cj.cnt = s_win[cpos].cnt;
+            cj.key = s_win[cpos].key;
+            cj.rk = s_win[cpos].rk;
+            cj.lx = s_win[cpos].lx;
+            cj.ly = s_win[cpos].ly;
+            cj.px = s_win[cpos].px;
+            cj.py = s_win[cpos].py;
+            const uint32_t p = cj.key >> 16, q = cj.key & 0xffffu;
+            // a second listing of a pair that is in the batch already: nothing to decide
+            bool dup = false;
+            for (uint32_t i = 0; i < nacc; ++i) dup |= s_acc[i].a == p && s_acc[i].b == q;
+            if (dup) continue;
+            if (tid == 0) {
+                bool stop = cj.cnt < candT_all || cj.cnt < min_freq || cj.cnt == 0ull;
+                for (uint32_t i = 0; i < nacc; ++i) stop |= q == s_acc[i].a || p == s_acc[i].b; // rule (1)
+                if (stop) s_stop = 1;
+            }
+            if (mine_in && mypos > pos && me_cnt == cj.cnt) { // rule (2): the pairs that tie with j
+                const uint32_t l = me_key >> 16, r = me_key & 0xffffu;
+                bool in_batch = false, left_new_blocks = false, right_new = false, right_new_ge = false;
+                for (uint32_t i = 0; i < nacc; ++i) {
+                    const AccEnt A = s_acc[i];
+                    in_batch |= A.a == l && A.b == r;
+                    if (A.b == l) left_new_blocks |= cmp_pre8(A.pc, A.lc, cj.px, cj.lx) != -1; // (c_i, .) vs (p, .)
+                    if (A.a == r) {
+                        right_new = true;
+                        const int cr = cmp_pre8(A.pc, A.lc, cj.py, cj.ly); // (., c_i) vs (., q)
+                        right_new_ge |= cr != -1;
+                    }
+                }
+                const uint32_t rl = me_rk >> 16, rp = cj.rk >> 16; // lexranks of l and p
+                const bool blocks = left_new_blocks || (right_new && (rl > rp || (rl == rp && right_new_ge)));
+                if (!in_batch && blocks) s_stop = 1; // (benign race: every writer stores 1)
+            }
+            __syncthreads();
+            if (s_stop) break;
+            if (tid == 0) {
+                s_acc[nacc] = AccEnt{p, q, cj.lx + cj.ly, cpos, pre8_concat(cj.px, cj.lx, cj.py)};
+                s_nacc = nacc + 1u;
+            }
+            if (p == q) { // rule (3): a run merge closes the batch
+                __syncthreads();
+                break;
+            }
+        }
+        __syncthreads();
+        uint32_t nacc = s_nacc;
+        if (nacc <= 1u) return;
+        // ---- the merged tokens of merges 1 .. nacc-1: one probe of the byte-string set each, side by side
+        if (tid >= 1 && (uint32_t)tid < nacc) {
+            const WinEnt w = s_win[s_acc[tid].win];
+            const uint32_t Lk = w.lx + w.ly;
+            const unsigned long long Hk = yb_hash_concat(w.hx, w.hy, w.ly);
+            uint32_t slot = yb_vset_home(Hk, Lk) & P.tt.vset_mask;
+            unsigned long long ve = ld_coherent(&P.tt.vset[slot]);
+            while (ve != VSET_EMPTY && (ve >> 32) != (Hk >> 32)) {
+                slot = (slot + 1) & P.tt.vset_mask;
+                ve = ld_coherent(&P.tt.vset[slot]);
+            }
+            s_pslot[tid] = slot;
+            s_phit[tid] = ve != VSET_EMPTY; // same 32 hash bits as an existing token: that merge opens the next batch (full compare there)
+            s_pH[tid] = Hk;
+            s_pL[tid] = Lk;
+        }
+        __syncthreads();
+        if (tid == 0) { // the batch ends in front of the first merge whose token cannot be created blindly
+            uint32_t keep = 1;
+            unsigned long long pool_at = s_pool;
+            for (uint32_t k = 1; k < nacc; ++k) {
+                bool bad = s_phit[k] != 0u || s_ntok + (k - 1u) >= YB_MAX_TOKENS || pool_at + s_pL[k] + 4ull > P.tt.pool_cap;
+                for (uint32_t k2 = 0; k2 < k; ++k2) bad |= s_pslot[k2] == s_pslot[k] || (s_pH[k2] == s_pH[k] && s_pL[k2] == s_pL[k]);
+                if (bad) break;
+                pool_at = (pool_at + s_pL[k] + 3ull) & ~3ull;
+                keep = k + 1u;
+            }
+            s_nacc = keep;
+        }
+        __syncthreads();
+        nacc = s_nacc;
+        if (nacc <= 1u) return;
+        if (tid >= 1 && (uint32_t)tid < nacc) { // commit merge k = tid
+            const uint32_t k = (uint32_t)tid;
+            const WinEnt w = s_win[s_acc[k].win];
+            uint32_t pool_at = s_pool;
+            for (uint32_t k2 = 1; k2 < k; ++k2) pool_at = (pool_at + s_pL[k2] + 3u) & ~3u;
+            const uint32_t cid = s_ntok + (k - 1u);
+            P.tt.off[cid] = pool_at;
+            P.tt.len[cid] = s_pL[k];
+            P.tt.rec[cid] = TokRec{0u, s_pL[k], s_pH[k], s_acc[k].pc, 0ull};
+            P.tt.vset[s_pslot[k]] = yb_vset_entry(cid, s_pH[k]);
+            const uint32_t ri = s_it - P.rec_base + (k - 1u);
+            P.rec_left[ri] = w.key >> 16;
+            P.rec_right[ri] = w.key & 0xffffu;
+            P.rec_merged[ri] = cid;
+            P.rec_count[ri] = w.cnt;
+            P.rec_live_slots[ri] = st->live_slots;
+            P.table.cnt[w.slot] = 0ull;
+            st->batch[k] = BatchMerge{w.key >> 16, w.key & 0xffffu, cid, 1u};
+            if (k == nacc - 1u) {
+                uint32_t pool_end = (pool_at + s_pL[k] + 3u) & ~3u;
+                st->pool_used = pool_end;
+                st->n_tokens = cid + 1u;
+                st->iter = s_it + (nacc - 1u);
+                st->n_batch = nacc;
+                st->best_count = w.cnt; // (the host's heuristics look at the lowest count selected so far)
+            }
+        }
+    }
 }
 __global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body<false>(P, best_ex_none()); }
 
@@ -2590,7 +2643,6 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_hist : nullptr};
-    const uint32_t newtok = (st->c_is_new && P.cas_first) ? C.c : EMPTY;
     C.mk = yb_memkey(C.a, C.b);
     C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
     const uint32_t mk = C.mk;
@@ -2631,7 +2683,11 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 #ifdef YB_PROFILE_SLOW // [5]: from the end of one rewrite to the start of the next (the wait for the tile, the match)
             if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
 #endif
-            slow_tile<WEIGHTED, AggV, HIST, true>(C, W, tile, len, r, na, nb, wave_sites, wave_freed, pmA, pmB);
+            {
+                TileRegs rr = r;
+                uint32_t len_io = len, fc = CAP;
+                slow_tile<WEIGHTED, AggV, HIST, true>(C, W, tile, len_io, rr, na, nb, wave_sites, wave_freed, fc, pmA, pmB);
+            }
 #ifdef YB_PROFILE_SLOW
             t_end = __builtin_readcyclecounter();
 #endif
@@ -2640,14 +2696,18 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 #ifdef YB_PROFILE_SLOW
     if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
 #endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, newtok, HIST ? s_hist : nullptr, C.a, C.b, C.c);
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, HIST ? s_hist : nullptr, C.a, C.b, C.c);
     }
     fused_select_tail(F);
 }
 
-// Split form, pass 1 with the skip index: a workgroup takes SCAN_CHUNK consecutive tiles, one thread tests one
-// tile's signature (12 B per tile: length + the 64-bit block that holds the pair's bits); the tiles that may contain
-// the pair are then read by the workgroup's waves in turn and matched exactly, as k_scan does.
+// ---------------------------------------------------------------- sparse form: skip index + rewrite, a BATCH of merges per launch
+// A workgroup takes runs of `chunk` consecutive tiles; one thread tests a tile's signature once per merge of the batch
+// (8 B per tile and merge: the 64-bit block that holds the pair's bits) and notes which merges may have sites there.  The
+// tiles that pass (~1 % per merge late in a job) are read by the workgroup's waves in turn; the merges a tile was noted for
+// are applied to it IN BATCH ORDER while it sits in registers (single_site_tile / slow_tile, DEFER forms) and the tile
+// is written back once.  The selection only batches merges whose relative order cannot matter for anything but this
+// (select_batch): a later merge of the batch never touches the tokens an earlier one consumes or creates a pair with.
 #ifdef YB_PROFILE_SCAN
 #ifdef YB_PROFILE_LAUNCH // (its own build: these same-address atomics sit in front of the workgroups' loads and distort the phase stamps)
 #define YB_LAUNCH_START(it) do { if (threadIdx.x == 0) atomicMin(&g_launch_prof[((it) & 0xFFFFu) * 4 + 0], wall_clock64()); } while (0)
@@ -2667,58 +2727,62 @@ __device__ unsigned long long g_scan_prof[MAX_LISTS_PROF * 8];
 #define YB_LAUNCH_END(it) do { } while (0)
 #endif
 struct ScanSkipParams {
-    ScanParams S;
-    ApplyParams A;                // for the inline single-site rewrite (deltas, signatures, counters)
+    ApplyParams A;                // tiles, lengths, where the deltas go, signatures, counters
     unsigned long long *blk_read; // [scan_blocks] tiles actually read (statistics; plain stores)
     uint32_t scan_blocks;         // workgroups [0, scan_blocks) scan; the rest of the grid runs k_rank_update's work
-    uint2 *dense;                 // != NULL: sparse merges -- workgroups with items append them to ONE list (one atomic each)
-    uint32_t dense_cap;
-    uint32_t kt;                  // signature tests per thread: a workgroup takes `chunk` <= threads * kt consecutive tiles at a time
+    uint32_t kt;                  // tiles per thread: a workgroup takes `chunk` <= threads * kt consecutive tiles at a time
     uint32_t chunk;               // ... (a multiple of 64; smaller than the workgroup when there are few tiles: a stream of 8,000 tiles
                                   // -- pooled words -- still spreads over 125 workgroups whose waves ALL rewrite matched tiles)
     RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
-    FuseParams F;                 // FULL form: the workgroup that finishes last selects the next merge (ticket != NULL)
+    FuseParams F;                 // ticket != NULL: the workgroup that finishes last selects the next batch
 };
 
-// INLINE: flat layout, a != b: a matched tile with exactly one site is rewritten right here in registers
-// (single_site_tile); only the rest (several sites, a == b runs, weighted words) goes to the worklist for k_slow.
-// FULL (sparse merges): the rest is rewritten here too (slow_tile) -- the few tiles involved do not need k_slow's
-// balancing, and one dependent launch with its own prologue, flush and drain disappears from every merge.  In this form
-// matched tiles are rewritten inside the candidate loop: a wave has only a handful of candidates and all their loads are
-// already in flight, so nothing queues behind the stores, and the second read of the tile is saved.
-template <bool INLINE, bool FULL, bool WEIGHTED, int NW>
+// what a workgroup keeps about the merges of the batch (LDS)
+struct BatchLds {
+    uint32_t a[KMAX], b[KMAX], c[KMAX];
+    uint32_t row[KMAX];            // signature block of the pair
+    unsigned long long mask[KMAX]; // its three bits inside the block
+};
+
+template <bool WEIGHTED, int NW>
 __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipParams &Q) { // false: stop flag set, nothing done (grid-uniform)
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
-    constexpr bool REWRITES = INLINE || FULL;
     constexpr int NT = NW * 64;                   // threads of the workgroup (NW waves)
     constexpr int KTM = scan_kt_max(NW);
-    static_assert(FULL || NW == WPB, "only the sparse form runs with wider workgroups");
-    __shared__ uint32_t s_n, s_hits, s_nrew;
-    __shared__ uint2 s_list[NT * KTM];
-    __shared__ uint2 s_rew[(REWRITES && !FULL) ? NT * KTM : 1];
-    __shared__ uint32_t s_keys[REWRITES ? AGG_N : 1];
-    __shared__ AggV s_vals[REWRITES ? AGG_N : 1];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[FULL ? NW : 1];
+    __shared__ uint32_t s_n;
+    __shared__ uint2 s_list[NT * KTM];            // (tile, live length | merges noted << 16)
+    __shared__ uint32_t s_keys[AGG_N];
+    __shared__ AggV s_vals[AGG_N];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[NW];
     __shared__ unsigned long long s_cnt[2];
-    const ScanParams &P = Q.S;
+    __shared__ BatchLds s_bm;
+    const ApplyParams &P = Q.A;
     YB_SCAN_STAMP(0);
-    // (the merge and the stop flags are read together: one round trip instead of two in front of the signature test)
-    const uint32_t st_stop = st->done | st->halt, st_a = st->a, st_b = st->b, st_c = st->c, st_new = st->c_is_new;
+    // (the batch and the stop flags are read together: one round trip in front of the signature test)
+    const uint32_t st_stop = st->done | st->halt;
+    const uint32_t nb_ = min(st->n_batch, (uint32_t)KMAX);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // (the LDS tables do not depend on the merge: they are cleared while the loads above are on their way)
+    if (blockIdx.x < Q.scan_blocks && threadIdx.x < (uint32_t)KMAX) {
+        const uint32_t k = threadIdx.x;
+        BatchMerge m = BatchMerge{0u, 0u, 0u, 0u};
+        if (k < nb_) m = st->batch[k];
+        const SigHash H = sig_hash(yb_pairkey(m.a, m.b));
+        s_bm.a[k] = m.a;
+        s_bm.b[k] = m.b;
+        s_bm.c[k] = m.c;
+        s_bm.row[k] = H.row;
+        s_bm.mask[k] = H.mask;
+    }
+    // (the LDS tables do not depend on the batch: they are cleared while the loads above are on their way)
     if (blockIdx.x < Q.scan_blocks) {
-        if (REWRITES) agg_init(Agg<AggV>{s_keys, s_vals, Q.A.agg_mask}, NT);
-        if (FULL) wave_lds_init(s_w[wib], lane);
+        agg_init(Agg<AggV>{s_keys, s_vals, P.agg_mask}, NT);
+        wave_lds_init(s_w[wib], lane);
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-        if (threadIdx.x == 0) {
-            s_n = 0;
-            s_hits = 0;
-            s_nrew = 0;
-        }
+        if (threadIdx.x == 0) s_n = 0;
     }
     if (st_stop) return false; // (the same answer in every workgroup: nobody takes a ticket)
-    if (FULL) YB_SCAN_STAMP(5); // (profile build: the merge has arrived)
+    YB_SCAN_STAMP(5); // (profile build: the batch has arrived)
 #ifdef YB_PROFILE_LAUNCH
     const uint32_t prof_it = st->iter;
     YB_LAUNCH_START(prof_it);
@@ -2731,276 +2795,136 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
         return true;
     }
     const uint32_t n_blocks = Q.scan_blocks;
-    SlowCtx<AggV> C{Q.A, Agg<AggV>{s_keys, s_vals, REWRITES ? Q.A.agg_mask : 0u}, st, st_a, st_b, st_c, 0u, 0u, lane,
+    const uint32_t nbatch = __builtin_amdgcn_readfirstlane(nb_);
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, P.agg_mask}, st, 0u, 0u, 0u, 0u, 0u, lane,
                     KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}};
-    const uint32_t a = C.a, b = C.b;
-    const uint32_t mk = yb_memkey(a, b);
-    C.mk = mk;
-    C.self = yb_pairkey(a, b);
-    const bool do_inline = FULL || (INLINE && a != b); // matched tiles are rewritten in this kernel
-    const bool single_ok = INLINE && a != b;
-    const SigProbe probe = sig_probe(Q.A.sig, Q.A.sig_stride, yb_pairkey(a, b));
-    WaveLds &W = s_w[FULL ? wib : 0];
+    WaveLds &W = s_w[wib];
     __syncthreads();
-    if (FULL) YB_SCAN_STAMP(6); // (profile build: LDS tables initialised)
-    uint2 *my_work = P.work + (size_t)blockIdx.x * P.seg;
+    YB_SCAN_STAMP(6); // (profile build: LDS tables initialised)
     unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
     const uint32_t kt = Q.kt;
     const uint32_t chunk = Q.chunk;
     const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
     for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += n_blocks) {
-        // all of this thread's signature words are requested before the first one is looked at
-        uint32_t len[KTM];
-        bool maybe[KTM];
+        // all of this thread's lengths are requested first, then the signature words merge by merge
+        uint32_t len[KTM], km[KTM];
         const uint32_t t_end = min(P.n_tiles, ch * chunk + chunk);
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
             const uint32_t t = ch * chunk + j * NT + threadIdx.x;
             len[j] = 0;
-            maybe[j] = false;
-            if (j < kt && t < t_end) { // (t_end: the end of this workgroup's run of tiles, or of the stream)
-                len[j] = P.tile_len[t];
-                maybe[j] = probe.maybe(t);
+            km[j] = 0;
+            if (j < kt && t < t_end) len[j] = P.tile_len[t]; // (t_end: the end of this workgroup's run of tiles, or of the stream)
+        }
+#pragma unroll 2
+        for (uint32_t k = 0; k < nbatch; ++k) {
+            const unsigned long long *rowp = P.sig + (size_t)s_bm.row[k] * P.sig_stride;
+            const unsigned long long mask = s_bm.mask[k];
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
+                const uint32_t t = ch * chunk + j * NT + threadIdx.x;
+                if (j < kt && t < t_end && (rowp[t] & mask) == mask) km[j] |= 1u << k;
             }
         }
         YB_SCAN_STAMP(1);
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
             if (j >= kt) break; // uniform
-            const bool mb = maybe[j] && len[j] != 0;
+            const bool mb = km[j] != 0 && len[j] != 0;
             const unsigned long long m = __ballot(mb);
             uint32_t base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (mb) s_list[base + bits_below_lane(m)] = make_uint2(ch * chunk + j * NT + threadIdx.x, len[j]);
+            if (mb) s_list[base + bits_below_lane(m)] = make_uint2(ch * chunk + j * NT + threadIdx.x, len[j] | (km[j] << 16));
         }
         __syncthreads();
         const uint32_t n = s_n;
         n_read += n;
-        // the candidate tiles, dealt to the waves; three candidates' data are in flight while one is matched (two in the
-        // FULL form: its rewrite code needs the registers, and a wave rarely has more than three candidates there)
-        constexpr bool DEEP = !FULL;
+        // the candidate tiles, dealt to the waves; the next candidate's data is in flight while one is matched and rewritten
+        // (a wave's candidates are the same in all its lanes: the descriptors live in scalar registers)
+        auto list_at = [&](uint32_t idx) -> uint2 {
+            const uint2 v = s_list[idx];
+            return make_uint2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
+        };
         uint32_t j = wib;
-        uint2 it0 = j < n ? s_list[j] : make_uint2(0u, 0u);
-        uint2 it1 = j + NW < n ? s_list[j + NW] : make_uint2(0u, 0u);
-        uint2 it2 = DEEP && j + 2 * NW < n ? s_list[j + 2 * NW] : make_uint2(0u, 0u);
-        TileRegs q0 = load_tile(P.tiles, it0.x, it0.y, lane);
-        TileRegs q1 = load_tile(P.tiles, it1.x, it1.y, lane);
-        TileRegs q2 = q1;
-        if constexpr (DEEP) q2 = load_tile(P.tiles, it2.x, it2.y, lane);
+        uint2 it0 = j < n ? list_at(j) : make_uint2(0u, 0u);
+        TileRegs q0 = load_tile(P.tiles, it0.x, it0.y & 0xffffu, lane);
         while (j < n) {
-            const uint2 cur = it0;
-            const TileRegs r = q0;
-            it0 = it1;
-            q0 = q1;
+            const uint32_t tile = it0.x;
+            uint32_t tlen = it0.y & 0xffffu, kmask = it0.y >> 16;
+            TileRegs r = q0;
             j += NW;
-            if constexpr (DEEP) {
-                it1 = it2;
-                q1 = q2;
-                if (j + 2 * NW < n) {
-                    it2 = s_list[j + 2 * NW];
-                    q2 = load_tile(P.tiles, it2.x, it2.y, lane);
-                }
-            } else if (j + NW < n) {
-                it1 = s_list[j + NW];
-                q1 = load_tile(P.tiles, it1.x, it1.y, lane);
+            if (j < n) { // (one candidate ahead: a second one in flight cost the flat form its fourth wave per SIMD)
+                it0 = list_at(j);
+                q0 = load_tile(P.tiles, it0.x, it0.y & 0xffffu, lane);
             }
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
-            // A rewrite stores to HBM, and on gfx950 stores queue in the same in-order vmcnt as this wave's prefetched
-            // loads: rewriting here would stall the scan behind every store.  Matched tiles are only noted; they are
-            // rewritten after the candidate loop, when no load of this wave is waiting behind the stores.
-            if (FULL) {
+            const uint32_t len_in = tlen;
+            uint32_t first_changed = CAP; // wave-uniform: the first slot of the tile that differs from what HBM holds
+            while (kmask) { // the merges this tile was noted for, in batch order
+                const int k = __ffs((int)kmask) - 1;
+                kmask &= kmask - 1u;
+                const uint32_t a = __builtin_amdgcn_readfirstlane(s_bm.a[k]), b = __builtin_amdgcn_readfirstlane(s_bm.b[k]); // (uniform: scalars)
+                const uint32_t mk = yb_memkey(a, b);
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+                const uint32_t na = next_lane(r.va.x, b0);
+                const uint32_t nb = next_lane(r.vb.x, PADPAD);
+                if (!__any(match4(r.va, na, mk) || match4(r.vb, nb, mk))) continue;
+                C.a = a;
+                C.b = b;
+                C.c = __builtin_amdgcn_readfirstlane(s_bm.c[k]);
+                C.mk = mk;
+                C.self = yb_pairkey(a, b);
                 const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
                 const unsigned long long holders = __ballot(mine != 0);
                 const int lane_s = __ffsll((long long)holders) - 1;
                 const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
-                bool handled = false;
-                if constexpr (INLINE) {
-                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile<AggV, false, WEIGHTED>(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
-                        handled = true;
+                if (a != b && __popcll(holders) == 1 && __popc(mm_s) == 1) {
+                    single_site_tile<AggV, false, WEIGHTED, true>(C, tile, tlen, r, lane_s, mm_s, wave_sites, wave_freed, first_changed);
 #ifdef YB_PROFILE_SCAN // how long until everything this tile stored is acknowledged (what a conservative vmcnt(0) costs)
-                        {
-                            const unsigned long long t0 = __builtin_readcyclecounter();
-                            vm_drain();
-                            const unsigned long long t1 = __builtin_readcyclecounter();
-                            if (lane == 0 && blockIdx.x == 7) {
-                                atomicAdd(&g_ss_prof[5], t1 - t0);
-                                atomicAdd(&g_ss_prof[6], 1ull);
-                            }
+                    {
+                        const unsigned long long t0 = __builtin_readcyclecounter();
+                        vm_drain();
+                        const unsigned long long t1 = __builtin_readcyclecounter();
+                        if (lane == 0 && blockIdx.x == 7) {
+                            atomicAdd(&g_ss_prof[5], t1 - t0);
+                            atomicAdd(&g_ss_prof[6], 1ull);
                         }
-#endif
                     }
+#endif
+                } else {
+                    slow_tile<WEIGHTED, AggV, false, false, true>(C, W, tile, tlen, r, na, nb, wave_sites, wave_freed, first_changed);
                 }
-                if (handled) {
-                } else if constexpr (FULL) {
-                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
-                } else if (lane == 0) {
-                    my_work[atomicAdd(&s_hits, 1u)] = cur;
-                }
-            } else if (do_inline) {
-                if (lane == 0) s_rew[atomicAdd(&s_nrew, 1u)] = cur;
-            } else {
-                if (lane == 0) my_work[atomicAdd(&s_hits, 1u)] = cur;
+            }
+            if (first_changed < (uint32_t)CAP) { // write the tile back: the 16-B groups from the first changed slot to the end of what is live
+                const uint32_t pad_end = (tlen + 7u) & ~7u;
+                uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+                const uint32_t gA = (uint32_t)lane * 8u, gB = 512u + (uint32_t)lane * 8u;
+                if (gA + 8u > first_changed && gA < pad_end) wb[lane] = r.va;
+                if (gB + 8u > first_changed && gB < pad_end) wb[64 + lane] = r.vb;
+                if (lane == 0) P.tile_len[tile] = tlen;
+                (void)len_in;
             }
         }
         __syncthreads();
         YB_SCAN_STAMP(2);
-        if (!FULL && do_inline) {
-            const uint32_t nr = s_nrew;
-            uint32_t k = wib;
-            uint2 w0 = k < nr ? s_rew[k] : make_uint2(0u, 0u);
-            uint2 w1 = k + NW < nr ? s_rew[k + NW] : make_uint2(0u, 0u);
-            TileRegs t0 = load_tile(P.tiles, w0.x, w0.y, lane); // L2 hits: the tile was read a moment ago
-            TileRegs t1 = load_tile(P.tiles, w1.x, w1.y, lane);
-            while (k < nr) {
-                const uint2 cur = w0;
-                const TileRegs r = t0;
-                w0 = w1;
-                t0 = t1;
-                k += NW;
-                if (k + NW < nr) {
-                    w1 = s_rew[k + NW];
-                    t1 = load_tile(P.tiles, w1.x, w1.y, lane);
-                }
-                const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-                const uint32_t na = next_lane(r.va.x, b0);
-                const uint32_t nb = next_lane(r.vb.x, PADPAD);
-                const uint32_t mine = match_mask8(r.va, na, mk) | (match_mask8(r.vb, nb, mk) << 8);
-                const unsigned long long holders = __ballot(mine != 0);
-                const int lane_s = __ffsll((long long)holders) - 1;
-                const uint32_t mm_s = __builtin_amdgcn_readlane(mine, lane_s < 0 ? 0 : lane_s);
-#ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)NW) YB_SCAN_STAMP(5 + (mm_s == 0xffffffffu));
-#endif
-                bool handled = false;
-                if constexpr (INLINE) {
-                    if (single_ok && __popcll(holders) == 1 && __popc(mm_s) == 1) {
-                        single_site_tile<AggV, false, WEIGHTED>(C, cur.x, cur.y, r, lane_s, mm_s, wave_sites, wave_freed);
-                        handled = true;
-                    }
-                }
-                if (handled) {
-                } else if constexpr (FULL) {
-                    slow_tile<WEIGHTED, AggV>(C, W, cur.x, cur.y, r, na, nb, wave_sites, wave_freed);
-                } else if (lane == 0) {
-                    my_work[atomicAdd(&s_hits, 1u)] = cur; // several sites: the general rewrite (k_slow)
-                }
-#ifdef YB_PROFILE_SCAN
-                if (k == (uint32_t)NW) YB_SCAN_STAMP(6);
-#endif
-            }
-            __syncthreads();
-        }
         YB_SCAN_STAMP(3);
-        if (threadIdx.x == 0) {
-            s_n = 0;
-            s_nrew = 0;
-        }
+        if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     }
-    if (!FULL && Q.dense) { // few tiles are left for k_slow: hand them over through one dense list (no per-workgroup prefix there)
-        __shared__ uint32_t s_base;
-        __syncthreads();
-        const uint32_t nh = s_hits;
-        if (nh) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&st->work_total, nh);
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < nh; i += BLOCK)
-                if (s_base + i < Q.dense_cap) Q.dense[s_base + i] = my_work[i];
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (!FULL) P.work_cnt[blockIdx.x] = s_hits;
-        if (Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
-    }
+    if (threadIdx.x == 0 && Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
     YB_SCAN_STAMP(4);
-    if (REWRITES) apply_epilogue<AggV, NT>(Q.A, C.agg, st, s_cnt, wave_sites, wave_freed, lane, (st_new && Q.A.cas_first) ? st_c : EMPTY);
+    apply_epilogue<AggV, NT>(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
     YB_SCAN_STAMP(7);
     YB_LAUNCH_END(prof_it);
     return true;
 }
-template <bool INLINE, bool FULL, bool WEIGHTED, int NW = WPB>
-// st (= Q.S.st) is a kernel argument of its own, the FIRST one: the library is built with kernel-argument preload for two
-// dwords (Makefile), so the pointer is in SGPRs when the wave starts and the read of the merge record does not have to wait
-// for the argument segment first -- one dependent trip less in front of every merge.
-__global__ __launch_bounds__(NW * 64, FULL ? 16 / NW : 1) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (FULL: <= 128 VGPRs, 16 waves per CU)
-    if (!scan_skip_block<INLINE, FULL, WEIGHTED, NW>(st, Q)) return;
-    if constexpr (FULL) fused_select_tail(Q.F);
-}
-
-// ================================================================ scans of the direct-indexed count matrix
-// Only the rows the host lists (rowmax >= what the scan is looking for).  One workgroup per row at a time; a row is read as
-// consecutive u64 (coalesced).  REBUILD: every pair with count >= T goes on the candidate list and the row's exact maximum
-// replaces its bound.  !REBUILD: the argmax by (count, ranks) over the listed rows, one partial per workgroup (k_select
-// finishes) -- the fallback when no candidate list can prove the maximum (first merges, tiny counts).
-struct DenseScanParams {
-    PairTable table;
-    const uint32_t *rows;
-    uint32_t n_rows;
-    const TokRec *rec;
-    Best *partials; // [gridDim.x] (!REBUILD)
-    DevState *st;
-    uint32_t keep_row; // REBUILD: the token of a merge that is selected but not applied yet -- its row is still empty and
-                       // about to fill: its bound (set by the selection) must stand
-};
-template <bool REBUILD>
-__global__ __launch_bounds__(BLOCK) void k_dense_scan(DenseScanParams P) {
-    __shared__ unsigned long long s_rmax[WPB];
-    __shared__ Best s_b[WPB];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const unsigned long long T = REBUILD ? P.table.cand_T : 0ull;
-    Best best{0ull, 0u, EMPTY, 0u, 0u};
-    if (!REBUILD && (P.st->done | P.st->halt)) return;
-    for (uint32_t r = blockIdx.x; r < P.n_rows; r += gridDim.x) {
-        const uint32_t o = P.rows[r], len = 2u * (o + 1u);
-        const unsigned long long *row = P.table.dense + (unsigned long long)o * (o + 1ull);
-        unsigned long long rmax = 0ull;
-        for (uint32_t j = threadIdx.x; j < len; j += BLOCK) {
-            const long long cn = (long long)row[j];
-            if (cn <= 0) continue;
-            const uint32_t key = tri_key(o, j);
-            if (REBUILD) {
-                rmax = (unsigned long long)cn > rmax ? (unsigned long long)cn : rmax;
-                if ((unsigned long long)cn >= T) {
-                    const uint32_t idx = atomicAdd(&P.table.cand_cs->n, 1u);
-                    if (idx < CAND_CAP) P.table.cand_list[idx] = (unsigned long long)key << 32; else P.table.cand_cs->overflow = 1u;
-                }
-            } else if ((unsigned long long)cn >= best.cnt) {
-                const Best e{(unsigned long long)cn, (P.rec[key >> 16].rank << 16) | P.rec[key & 0xffffu].rank, key, 0u, 0u};
-                if (best_gt(e, best)) best = e;
-            }
-        }
-        if (REBUILD) {
-            rmax = best_wave_reduce(Best{rmax, 0u, 0u, 0u, 0u}).cnt;
-            if (lane == 0) s_rmax[wib] = rmax;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                for (int w = 1; w < WPB; ++w) rmax = s_rmax[w] > rmax ? s_rmax[w] : rmax;
-                if (o != P.keep_row) P.table.rowmax[o] = rmax;
-            }
-            __syncthreads();
-        }
-    }
-    if (!REBUILD) {
-        best = best_wave_reduce(best);
-        if (lane == 0) s_b[wib] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 1; i < WPB; ++i)
-                if (best_gt(s_b[i], best)) best = s_b[i];
-            P.partials[blockIdx.x] = best;
-        }
-    }
-}
-// debug: two matrices over the same tokens, entry by entry
-__global__ __launch_bounds__(BLOCK) void k_dense_compare(const unsigned long long *a, const unsigned long long *b, unsigned long long n, unsigned long long *mismatches) {
-    unsigned long long bad = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) bad += a[i] != b[i];
-    if (bad) atomicAdd(mismatches, bad);
+// st (= Q.A.st) is a kernel argument of its own, the FIRST one: the library is built with kernel-argument preload for two
+// dwords (Makefile), so the pointer is in SGPRs when the wave starts and the read of the batch record does not have to wait
+// for the argument segment first -- one dependent trip less in front of every launch.
+template <bool WEIGHTED, int NW = WPB>
+__global__ __launch_bounds__(NW * 64, NW == WPB ? 3 : 16 / NW) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (<= 128 VGPRs, 16 waves per CU)
+    if (!scan_skip_block<WEIGHTED, NW>(st, Q)) return;
+    fused_select_tail(Q.F);
 }
 
 // ================================================================ table growth: re-insert live entries (count != 0)

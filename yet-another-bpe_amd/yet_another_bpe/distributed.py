@@ -220,7 +220,6 @@ class ShardedRunner:
             options: dict | None = None) -> dict:
         ctx = self._context()
         ctx.set_option("event_sample", event_sample)
-        ctx.set_option("skip_index", 1)
         for k, v in (options or {}).items():
             ctx.set_option(k, v)
         ctx.set_vocab(self.base)  # resets tokens / merge state; the communicator stays attached
