@@ -143,7 +143,7 @@ struct yabpe_ctx {
     uint8_t *pt_cls = nullptr;                // class per code point (unicode_classes.inc expanded), built on first use
     // misc device scratch
     unsigned long long *scratch64 = nullptr;  // 16 x u64: [0] live sum [1] freq overflow [2,3] long words [4,5,6] verify/checksum
-                                              // [7] comm_max [8] exchange record count [9] local count-table entries
+                                              // [7] comm_max [8] exchange record count [9] local count-table entries [10..12] comm_max3
     unsigned long long *blk_stats = nullptr;  // 2 x MAX_APPLY_BLOCKS per-workgroup counters of k_apply
     uint32_t blk_used = 0;                    // largest grid that wrote blk_stats since they were last folded
     bool split_mode = false;         // the sparse form (skip index + batches of merges per launch) instead of the streaming one
@@ -539,6 +539,19 @@ int comm_max(yabpe_ctx *c, unsigned long long v, unsigned long long *out) {
     HIPCHK(c, hipMemcpyAsync(all.data(), c->xsmall, 8 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto x : all) *out = std::max(*out, x);
+    return 0;
+}
+
+// max over ranks of three small integers in ONE exchange (host-visible); identity on one GPU
+int comm_max3(yabpe_ctx *c, unsigned long long v[3]) {
+    if (!c->multi) return 0;
+    HIPCHK(c, hipMemcpyAsync(&c->scratch64[10], v, 24, hipMemcpyHostToDevice, c->stream));
+    TRY(comm_allgather(c, &c->scratch64[10], c->xsmall, 24));
+    std::vector<unsigned long long> all(3 * (size_t)c->n_ranks);
+    HIPCHK(c, hipMemcpyAsync(all.data(), c->xsmall, 24 * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->n_ranks; ++r)
+        for (int k = 0; k < 3; ++k) v[k] = std::max(v[k], all[3 * (size_t)r + k]);
     return 0;
 }
 
@@ -1437,6 +1450,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     unsigned long long prev_best = 0;
     uint64_t launches_sparse = 0;
     uint32_t cand_n_all = 0;  // length of the candidate list at the last read (multi-GPU: of the longest replica's)
+    bool sparse_global = false;  // the sparse form has been called for (by any rank)
     c->use_cand = false;
     c->pending = false;
     while (!finished) {
@@ -1453,14 +1467,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         const uint32_t apply_grid = count_grid(c);
         // sites per merge never increase (the best count is monotone): once they are sparse relative to the
         // number of tiles, switch from the streaming kernel to the skip index + rewrite for good
-        const int64_t split_opt = optv(c, "split", -1);  // -1 auto, 0 never, 1 always
-        if (split_opt >= 0)
-            c->split_mode = split_opt == 1;
-        // (pooled words: the count is weighted, what matters is how many resident sites the last merge had)
-        else if (!c->split_mode && h->iter > rec_base &&
-                 (c->weighted && h->sites ? h->sites : h->best_count) * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100))
-            c->split_mode = true;
-        if (!c->n_tiles) c->split_mode = false;
+        const int64_t split_opt = optv(c, "split", -1);  // -1 auto (see want_sparse below: for good, and for all ranks), 0 never, 1 always
+        const bool sparse_now = split_opt >= 0 ? split_opt == 1 : sparse_global;
+        c->split_mode = sparse_now && c->n_tiles;  // (a rank without tiles launches no apply kernel, but selects like the others)
         if (!tail_marked && i >= num_merges / 2) {  // (measurement: the second half of this call's merges)
             tail_marked = true;
             tail_at = i;
@@ -1508,14 +1517,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             }
         }
         // merges one selection may take: a batch in the sparse form (the streaming form applies one merge per launch)
-        const uint32_t kmax = c->split_mode ? (uint32_t)std::max<int64_t>(1, std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX))) : 1u;
+        const uint32_t kmax = sparse_now ? (uint32_t)std::max<int64_t>(1, std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX))) : 1u;
         if (kmax != c->kmax_now) {
             HIPCHK(c, hipMemcpyAsync(&c->st->kmax, &kmax, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             c->kmax_now = kmax;
             h->kmax = kmax;
         }
         // records for everything the launches of this round can select
-        const uint32_t n_launch = (first_round && !c->split_mode) ? std::min<uint32_t>(check, 8) : check;
+        const uint32_t n_launch = (first_round && !sparse_now) ? std::min<uint32_t>(check, 8) : check;  // (the same on every rank: a launch is an exchange)
         first_round = false;
         c->rec_n_live = i;
         TRY(ensure_records((uint32_t)std::min<uint64_t>(num_merges, (uint64_t)i + (uint64_t)(n_launch + 2) * kmax)));
@@ -1582,14 +1591,22 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             h->xmax = 0;
         }
         cand_n_all = h->cand_n;
+        // does this rank's shard call for the sparse form?  (sites per merge never increase -- the best count is monotone: once
+        // they are sparse relative to the number of tiles.  Pooled words: the count is weighted, what matters is how many
+        // resident sites the last merge had.)
+        unsigned long long want_sparse = (c->n_tiles && h->iter > rec_base &&
+                 (c->weighted && h->sites ? h->sites : h->best_count) * 100 < (unsigned long long)c->n_tiles * (unsigned long long)optv(c, "split_pct", 100)) ? 1 : 0;
         if (c->multi) {  // replicas must be in lockstep: same merge count, same flags
-            unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1), mx = 0;
-            TRY(comm_max(c, sig, &mx));
-            if (mx != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, mx);
-            unsigned long long cn_all = 0;
-            TRY(comm_max(c, h->cand_n, &cn_all));
-            cand_n_all = (uint32_t)cn_all;
+            unsigned long long sig = ((unsigned long long)h->iter << 8) | (h->done ? 1u : 0u) | ((unsigned long long)(h->halt & 0x3f) << 1);
+            // ... and agree on what must not differ between them: the batch limit follows the form (any rank sparse: all of
+            // them), the candidate list is rebuilt for the longest replica's length
+            unsigned long long v[3] = {sig, h->cand_n, want_sparse};
+            TRY(comm_max3(c, v));
+            if (v[0] != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, v[0]);
+            cand_n_all = (uint32_t)v[1];
+            want_sparse = v[2];
         }
+        if (want_sparse) sparse_global = true;
         if (h->halt == HALT_RESCAN) {  // the candidate set could not prove the maximum: redo that merge with the full scan
             h->halt = 0; h->halt_req = 0;
             TRY(state_push(c));
@@ -2061,7 +2078,7 @@ static int comm_attach(yabpe_ctx *c, int rank, int n_ranks) {
     return 0;
 }
 static int comm_finish(yabpe_ctx *c) {
-    TRY(dmalloc(c, &c->xsmall, (uint64_t)c->n_ranks));
+    TRY(dmalloc(c, &c->xsmall, 4 * (uint64_t)c->n_ranks));
     TRY(comm_buffers(c, (uint32_t)optv(c, "delta_cap", 16384)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return YABPE_OK;
