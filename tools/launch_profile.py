@@ -28,16 +28,25 @@ with _native.Context() as g:
         out = np.zeros(65536 * 4, dtype=np.uint64)
         L.yabpe_debug_launch_profile(ctypes.c_void_p(out.ctypes.data), 0)
 raw = out.reshape(65536, 4)
-print("raw rows 25000..25003:", raw[25000:25004].tolist())
 p = raw.astype(np.float64) / 100.0  # us
-ok = (out.reshape(65536, 4)[:, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)) & (out.reshape(65536, 4)[:, 1] != 0)
-for lo, hi in [(300, 1000), (1000, 3000), (3000, 8000), (8000, 12000), (12000, 20000), (20000, 31990)]:
-    idx = np.arange(lo, hi)
-    idx = idx[ok[idx] & ok[idx + 1] & (p[idx, 3] > 0)]
-    wg = p[idx, 1] - p[idx, 0]              # first workgroup start -> last workgroup end (apply + flush + ticket wait of the others)
-    sel = p[idx, 3] - p[idx, 1]             # -> DevState of the next merge stored
-    gap = p[idx + 1, 0] - p[idx, 3]         # -> first workgroup of the next launch
-    per = p[idx + 1, 0] - p[idx, 0]
-    good = (gap > 0) & (gap < 200) & (per < 1000)
-    print(f"merges {lo:6d}-{hi:6d} n={good.sum():6d}: workgroups {np.median(wg[good]):6.2f}  selection tail {np.median(sel[good]):6.2f}  "
-          f"between launches {np.median(gap[good]):6.2f}  period {np.median(per[good]):6.2f} us (medians; mean period {per[good].mean():.2f})")
+valid = np.nonzero((raw[:, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)) & (raw[:, 1] != 0) & (raw[:, 3] != 0))[0]  # row = DevState::iter when the launch started
+nxt = valid[1:]
+cur = valid[:-1]
+batch = nxt - cur                      # merges the launch's selection added = what the NEXT launch applies
+wg = p[cur, 1] - p[cur, 0]             # first workgroup start -> last workgroup end (apply + flush + ticket wait of the others)
+sel = p[cur, 3] - p[cur, 1]            # -> DevState of the next batch stored
+gap = p[nxt, 0] - p[cur, 3]            # -> first workgroup of the next launch
+per = p[nxt, 0] - p[cur, 0]
+applied = np.concatenate([[1], batch[:-1]])  # merges this launch applied (selected by the launch before it)
+good = (gap > 0) & (gap < 500) & (per < 5000)
+for lo, hi in [(100, 300), (300, 1000), (1000, 3000), (3000, 8000), (8000, 12000), (12000, 20000), (20000, 31990)]:
+    m = good & (cur >= lo) & (cur < hi)
+    if not m.any():
+        continue
+    print(f"merges {lo:6d}-{hi:6d}: launches {m.sum():5d} mean batch {applied[m].mean():.2f} | medians: workgroups {np.median(wg[m]):7.2f}  selection tail {np.median(sel[m]):6.2f}  "
+          f"between launches {np.median(gap[m]):5.2f}  period {np.median(per[m]):7.2f} us | mean period {per[m].mean():7.2f} us = {per[m].sum() / applied[m].sum():6.2f} us per merge")
+    for k in (1, 2, 3, 4, 6, 8):
+        mk = m & (applied == k)
+        ms = m & (batch == k)
+        if mk.sum() >= 5:
+            print(f"      launches applying {k} merges: n {mk.sum():5d}  workgroups {np.median(wg[mk]):7.2f} (mean {wg[mk].mean():7.2f})   |  selecting {k}: n {ms.sum():5d} selection tail {np.median(sel[ms]) if ms.any() else 0:6.2f}")

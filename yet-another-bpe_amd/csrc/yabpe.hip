@@ -1545,7 +1545,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         const bool fuse = can_fuse(c);
         const uint32_t tok_upper0 = h->n_tokens;
         uint32_t launched = 0;
-        if (c->pending && (!fuse || i >= num_merges)) {  // leave the fused form: the selected merges are applied on their own
+        if (c->pending && !fuse) {  // leave the fused form: the selected merges are applied on their own
             TRY(launch_apply(c, rec_base, tok_upper0 + kmax, apply_grid, sample(i ? i - 1 : 0), false));
             c->pending = false;
         }
@@ -1558,8 +1558,13 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             ++launched;
             const uint32_t tok_upper = tok_upper0 + (launched + 1u) * kmax + 1u;
             if (fuse) {
+                // (i == num_merges: every merge is selected, the last ones are pending -- this launch applies them and its
+                // selection finds the limit reached: done.  An apply launch must never run twice on one selection: in the
+                // multi-GPU form the send buffer would still hold the records of the first time.)
+                const bool last = i >= num_merges;
                 TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i - 1), true));
                 if (kmax == 1) ++i; else ++launches_sparse;
+                if (last) break;
             } else {
                 TRY(launch_select(c, rec_base));
                 TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i), false));
@@ -1871,14 +1876,27 @@ int yabpe_verify_table(yabpe_ctx *c, uint64_t *out_mismatches) {
     TRY(table_alloc(c, scratch, c->table_cap, &c->scratch64[4]));
     TRY(launch_count(c, scratch));
     uint32_t grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, c->table_cap / BLOCK));
-    CmpParams A{c->table, scratch, &c->scratch64[5]};
+    const bool dbg = getenv("YABPE_DEBUG_VERIFY") != nullptr;
+    unsigned long long *dump = nullptr;
+    if (dbg) {
+        TRY(dmalloc(c, &dump, 48));
+        HIPCHK(c, hipMemsetAsync(dump, 0, 48 * 8, c->stream));
+    }
+    CmpParams A{c->table, scratch, &c->scratch64[5], dump};
     hipLaunchKernelGGL(k_table_compare, dim3(grid), dim3(BLOCK), 0, c->stream, A);
-    CmpParams B{scratch, c->table, &c->scratch64[5]};
+    CmpParams B{scratch, c->table, &c->scratch64[5], dump};
     hipLaunchKernelGGL(k_table_compare, dim3(grid), dim3(BLOCK), 0, c->stream, B);
     HIPCHK(c, hipGetLastError());
     unsigned long long mm = 0;
     HIPCHK(c, hipMemcpyAsync(&mm, &c->scratch64[5], 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dbg) {
+        unsigned long long d[48];
+        HIPCHK(c, hipMemcpy(d, dump, sizeof d, hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < 16 && i < mm; ++i)
+            fprintf(stderr, "[yabpe verify r%d] key (%llu,%llu) first %lld second %lld\n", c->rank, d[3 * i] >> 16, d[3 * i] & 0xffffull, (long long)d[3 * i + 1], (long long)d[3 * i + 2]);
+        dfree(dump);
+    }
     table_free(scratch);
     // the recount may have raised halt_req on the scratch table; it is not a training halt
     HIPCHK(c, hipMemsetAsync(&c->st->halt_req, 0, 4, c->stream));

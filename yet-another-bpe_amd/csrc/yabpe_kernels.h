@@ -1834,46 +1834,21 @@ __device__ __forceinline__ int cmp_pre8(unsigned long long px, uint32_t lx, unsi
     return 2;
 }
 
-// One workgroup: commits a pending halt, folds the apply pass's counters, finds the next merge (EVAL: on the candidate list,
-// else among the argmax partials), applies the stop rules and creates the merged token; EVAL with kmax > 1: extends the
-// selection to a batch (see above).  Runs as k_select, as the tail of k_argmax_cand in its last workgroup, or as the tail of
-// the fused per-merge launch.  This is a chain of dependent memory round trips on the critical path of every launch, so it
-// is kept short:
-//   - thread 0 keeps the DevState fields it needs in registers, and everything that does not depend on the winner (DevState,
-//     block counters, partials, the list) is requested in the same round;
-//   - a merged token is created from the two tokens' records: its hash follows from theirs (yb_hash_concat), one probe of
+// The selection as a launch of its own (k_select, or the last workgroup of k_argmax_cand): one workgroup commits a pending
+// halt, folds the apply pass's counters, reduces the argmax partials, applies the stop rules and creates the merged token.
+// ONE merge (DevState::batch[0]).  Used when no merge is pending (start of a job, after a halt) and when no candidate list
+// can prove the maximum; the per-batch launches end with select_eval below instead.
+//   - thread 0 keeps the DevState fields it needs in registers and writes back what it changes;
+//   - the merged token is created from the two tokens' records: its hash follows from theirs (yb_hash_concat), one probe of
 //     the byte-string set says whether those bytes are already a token (trainer.py:298), and its bytes are written by the
 //     NEXT launch (rank_update_block) -- the winner's bytes are never read here unless hash and length match an entry.
-// `mine`: this thread's candidate from the caller.
-template <bool EVAL>
-__device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) {
+__device__ __forceinline__ void select_body(const SelectParams &P) {
     __shared__ Best s_b[WPB];
-    __shared__ uint32_t s_flag, s_slot, s_eq, s_lx, s_ly, s_have;
-    __shared__ unsigned long long s_fold[2], s_hx, s_hy, s_ent;
-    // batch selection
-    __shared__ WinEnt s_win[EVAL ? WIN : 1];
-    __shared__ AccEnt s_acc[KMAX];
-    __shared__ unsigned long long s_lvl[WPB], s_pH[KMAX];
-    __shared__ uint32_t s_hset[EVAL ? 2 * WIN : 1];
-    __shared__ uint32_t s_nwin, s_ext, s_stop, s_nacc, s_cpos, s_pslot[KMAX], s_phit[KMAX], s_pL[KMAX];
-    __shared__ uint32_t s_it, s_ntok, s_pool;
-    __shared__ unsigned long long s_px, s_py;
+    __shared__ uint32_t s_flag, s_slot, s_eq, s_lx, s_ly;
+    __shared__ unsigned long long s_fold[2], s_hx, s_hy, s_px, s_py, s_ent;
     DevState *st = P.st;
     const int tid = threadIdx.x;
     YB_SEL_STAMP(1);
-    // ---- round trip 1: everything that depends on nothing.  EVAL (fused form): the first 4 x BLOCK entries of the
-    // candidate list and its length (the list's storage exists up to CAND_CAP; what lies past n is ignored) ...
-    unsigned long long e[4] = {0ull, 0ull, 0ull, 0ull}, cn[4] = {0ull, 0ull, 0ull, 0ull};
-    uint32_t n_list = 0, kmax = 1;
-    if constexpr (EVAL) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
-        n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
-        kmax = min(st->kmax, (uint32_t)KMAX);
-    }
-    // ... the fields of DevState the selection needs (thread 0 keeps them in registers and writes back what it changes,
-    // field by field: a working copy of the whole struct was 36 registers in every lane, and in LDS it made thread 0's
-    // serial part a chain of LDS round trips) ...
     uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0, d_prev_batch = 0;
     unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0;
     unsigned long long candT = 0;
@@ -1901,45 +1876,12 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
         s_fold[0] = 0;
         s_fold[1] = 0;
         s_flag = 0;
-        s_have = 0;
-        s_nwin = 0;
-        s_ext = 0;
-        s_nacc = 0;
     }
-    // ... and the counters of the last apply pass (one slot per workgroup), summed and cleared further down
-    unsigned long long vx[4], vy[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t i = k * BLOCK + tid;
-        vx[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i]) : 0ull;
-        vy[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i + 1]) : 0ull;
-    }
-    // ---- round trip 2 (EVAL): the counts of this thread's entries (the slot rides in the list).  Round trip 3: ranks, lengths, hashes and prefixes (a token's record is 32 B) only for the
-    // entries of the window (kmax > 1: the highest count levels, at most WIN entries) or for those that hold the maximum
-    // count: every scattered load of this ONE workgroup costs a cycle of its CU's address path.
-    uint32_t n_win = 0, mypos = 0xffffffffu; // window entries; this thread's entry (tid < n_win) in selection order
-    if constexpr (EVAL) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cn[k] = 0ull;
-            if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(pt_count_ptr(P.table, e[k]));
-        }
-    }
-    // (the counters are summed while the counts are on their way: their registers are free for what follows)
+    // the counters of the last apply pass (one slot per workgroup): summed and cleared
     unsigned long long fa = 0, ff = 0;
     {
         unsigned long long *bs = P.blk_stats;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = k * BLOCK + tid;
-            fa += vx[k];
-            ff += vy[k];
-            if (i < P.n_blk && (vx[k] | vy[k])) {
-                bs[2 * i] = 0ull;
-                bs[2 * i + 1] = 0ull;
-            }
-        }
-        for (uint32_t i = 4 * BLOCK + tid; i < P.n_blk; i += BLOCK) { // (grids beyond 1,024 workgroups: the streaming phase)
+        for (uint32_t i = tid; i < P.n_blk; i += BLOCK) {
             const unsigned long long x = ld_coherent(&bs[2 * i]), y = ld_coherent(&bs[2 * i + 1]);
             fa += x;
             ff += y;
@@ -1949,138 +1891,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             }
         }
     }
-    if constexpr (EVAL) {
-        unsigned long long cmax = 0ull;
-        if (n_list != 0xdeadbeefu) YB_SEL_STAMP(9); // (profile build: list length + entries have arrived, counts requested)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((long long)cn[k] <= 0) cn[k] = 0ull;
-            cmax = cn[k] > cmax ? cn[k] : cmax;
-        }
-        if (cmax != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(10); // (counts have arrived)
-        // The window: the pairs on the highest count levels, whole levels, at most WIN pairs.  A pair can be on the list more
-        // than once (cand_note) and how often differs from replica to replica (multi-GPU), so the window is built from DISTINCT
-        // pairs -- a small hash set in LDS keeps the repeats out -- and every decision below depends on the pairs and their counts
-        // only: all ranks walk the same window and select the same batch.  Entries past the first 4 x BLOCK (a long list: rare,
-        // the host rebuilds it before) are streamed from memory in every step instead of sitting in registers.
-        unsigned long long L = 0ull, bound = ~0ull; // levels below `bound` are still to be visited
-        uint32_t total = 0;
-        bool win_ok = false;
-        const uint32_t max_levels = kmax > 1u ? kmax : 1u;
-        constexpr uint32_t HSET = 2 * WIN;
-        for (uint32_t hidx = tid; hidx < HSET; hidx += BLOCK) s_hset[hidx] = EMPTY;
-        for (uint32_t lv = 0; lv < max_levels; ++lv) {
-            unsigned long long m = 0ull;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m = (cn[k] < bound && cn[k] > m) ? cn[k] : m;
-            for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) { // (long list)
-                const long long c = (long long)ld_coherent(pt_count_ptr(P.table, ld_coherent(&P.table.cand_list[ti])));
-                if (c > 0 && (unsigned long long)c < bound && (unsigned long long)c > m) m = (unsigned long long)c;
-            }
-            m = best_wave_reduce(Best{m, 0u, 0u, 0u, 0u}).cnt;
-            __syncthreads(); // (s_lvl of the last round is read)
-            if ((tid & 63) == 0) s_lvl[tid >> 6] = m;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < WPB; ++w) m = s_lvl[w] > m ? s_lvl[w] : m;
-            if (m == 0ull) break; // nothing below
-            if (lv == 0) cmax = m;
-            if (kmax <= 1u) break; // (one merge per selection: no window)
-            // this level's pairs -> window (first listing of a pair only)
-            auto put = [&](unsigned long long ent, unsigned long long c) {
-                const uint32_t key = (uint32_t)(ent >> 32);
-                uint32_t h = hash32(key) & (HSET - 1u);
-                for (uint32_t probe = 0; probe < HSET; ++probe) {
-                    const uint32_t was = atomicCAS(&s_hset[h], EMPTY, key);
-                    if (was == key) return; // listed twice
-                    if (was == EMPTY) {
-                        const uint32_t idx = atomicAdd(&s_nwin, 1u);
-                        if (idx < (uint32_t)WIN) {
-                            s_win[idx].cnt = c;
-                            s_win[idx].key = key;
-                            s_win[idx].slot = (uint32_t)ent;
-                        }
-                        return;
-                    }
-                    h = (h + 1u) & (HSET - 1u);
-                }
-                s_nwin = WIN + 1u; // (the set is full: more distinct pairs than a window holds)
-            };
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (cn[k] == m) put(e[k], m);
-            for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) {
-                const unsigned long long ent = ld_coherent(&P.table.cand_list[ti]);
-                if (ld_coherent(pt_count_ptr(P.table, ent)) == m) put(ent, m);
-            }
-            __syncthreads();
-            const uint32_t now = s_nwin;
-            if (now > (uint32_t)WIN) break; // (this level does not fit: the window ends above it)
-            total = now;
-            L = m;
-            win_ok = true;
-            bound = m;
-            if (total >= 4u * kmax) break; // plenty
-        }
-        (void)L;
-        if (win_ok) {
-            // ONE entry per thread fetches its two token records (a round trip for all)
-            if ((uint32_t)tid < total) {
-                const uint32_t key = s_win[tid].key;
-                const unsigned long long *qx = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key >> 16]);
-                const unsigned long long *qy = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key & 0xffffu]);
-                const unsigned long long ax = ld_coherent(qx), hx = ld_coherent(qx + 1), px = ld_coherent(qx + 2);
-                const unsigned long long ay = ld_coherent(qy), hy = ld_coherent(qy + 1), py = ld_coherent(qy + 2);
-                s_win[tid].rk = ((uint32_t)ax << 16) | ((uint32_t)ay & 0xffffu);
-                s_win[tid].lx = (uint32_t)(ax >> 32);
-                s_win[tid].ly = (uint32_t)(ay >> 32);
-                s_win[tid].hx = hx;
-                s_win[tid].hy = hy;
-                s_win[tid].px = px;
-                s_win[tid].py = py;
-            }
-            __syncthreads();
-            n_win = total;
-            // selection order by counting: an entry's position is the number of entries in front of it
-            if ((uint32_t)tid < n_win) {
-                const unsigned long long c0 = s_win[tid].cnt;
-                const uint32_t r0 = s_win[tid].rk;
-                uint32_t pos = 0;
-                for (uint32_t u = 0; u < n_win; ++u) {
-                    const unsigned long long cu = s_win[u].cnt;
-                    const uint32_t ru = s_win[u].rk;
-                    pos += (cu > c0) || (cu == c0 && (ru > r0 || (ru == r0 && u < (uint32_t)tid)));
-                }
-                mypos = pos;
-                if (pos == 0) {
-                    const WinEnt w = s_win[tid];
-                    mine = BestEx{Best{w.cnt, w.rk, w.key, w.slot, 0u}, w.hx, w.hy, w.lx, w.ly, 1u};
-                    s_px = w.px;
-                    s_py = w.py;
-                }
-            }
-        } else { // (cmax is the maximum over the whole list: level 0 of the loop above)
-            if (cmax) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (cn[k] != cmax) continue;
-                    const uint32_t key = (uint32_t)(e[k] >> 32);
-                    uint32_t rl, rr, lx, ly;
-                    unsigned long long hx, hy;
-                    ld_rec_coherent(&P.tt.rec[key >> 16], rl, lx, hx);
-                    ld_rec_coherent(&P.tt.rec[key & 0xffffu], rr, ly, hy);
-                    const Best b{cn[k], (rl << 16) | rr, key, (uint32_t)e[k], 0u};
-                    if (best_gt(b, mine.b)) mine = BestEx{b, hx, hy, lx, ly, 1u};
-                }
-            }
-            if (n_list > 4u * BLOCK) { // a long list (the host keeps it shorter than this): the rest, four per thread at a time
-                const BestEx more = cand_list_best<1>(P.table, P.tt.rec, n_list, 4u * BLOCK + tid, BLOCK); // (rare: one entry at a time keeps the registers of the common path)
-                if (best_gt(more.b, mine.b)) mine = more;
-            }
-        }
-        if (mine.b.cnt != 0xdeadbeefdeadbeefull) YB_SEL_STAMP(11); // (records have arrived)
-    }
-    Best best = mine.b;
+    Best best{0ull, 0u, EMPTY, 0u, 0u};
     for (uint32_t i = tid; i < P.n_partials; i += BLOCK) {
         const Best pe = best_load_coherent(&P.partials[i]);
         if (best_gt(pe, best)) best = pe;
@@ -2157,16 +1968,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
     YB_SEL_STAMP(3);
     const Best win = s_b[0];
     const uint32_t x = win.key >> 16, y = win.key & 0xffffu;
-    // the two tokens' lengths and hashes: in the registers of the thread whose candidate won, or one more round trip
-    if (EVAL && n_win && mine.have && mine.b.key == win.key && mine.b.cnt == win.cnt) { // (the window's first entry: one thread; it has left the prefixes too)
-        s_hx = mine.hx;
-        s_hy = mine.hy;
-        s_lx = mine.lx;
-        s_ly = mine.ly;
-        s_have = 1;
-    }
-    __syncthreads();
-    if (!s_have && tid < 2) { // (no window: the winner's two records, prefixes included -- one more round trip)
+    if (tid < 2) { // the two tokens' records
         const TokRec r = P.tt.rec[tid ? y : x];
         if (tid) { s_hy = r.hash; s_ly = r.len; s_py = r.pre8; } else { s_hx = r.hash; s_lx = r.len; s_px = r.pre8; }
     }
@@ -2240,7 +2042,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             P.tt.off[cid] = pu;
             P.tt.len[cid] = L;
             P.tt.rec[cid] = TokRec{0u, L, H, pre8_concat(s_px, s_lx, s_py), 0ull};
-            st_coherent(&P.tt.vset[s_slot], yb_vset_entry(cid, H)); // (the probes of the rest of the batch may pass this slot)
+            P.tt.vset[s_slot] = yb_vset_entry(cid, H);
             is_new = 1;
         }
         if (ok) {
@@ -2263,158 +2065,486 @@ __device__ __forceinline__ void select_body(const SelectParams &P, BestEx mine) 
             st->iter = d_iter + 1;
             st->pool_used = is_new ? ((pu + L + 3u) & ~3u) : pu;
             st->n_tokens = d_n_tokens + is_new;
-            // may the batch go on?  (rule (3); the walk needs the window)
-            if (EVAL && is_new && x != y && n_win > 1u && kmax > 1u && d_iter + 1u < d_num_merges) {
-                s_ext = 1;
-                s_it = d_iter + 1u;
-                s_ntok = d_n_tokens + 1u;
-                s_pool = (pu + L + 3u) & ~3u;
-                s_acc[0] = AccEnt{x, y, L, 0u, pre8_concat(s_px, s_lx, s_py)};
-                s_pH[0] = H;
-                s_pL[0] = L;
-                s_pslot[0] = s_slot;
-                s_nacc = 1u;
-            }
 #ifdef YB_PROFILE_LAUNCH
             g_launch_prof[(d_iter & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
 #endif
         }
     }
     YB_SEL_STAMP(7);
-    if constexpr (EVAL) {
-        __syncthreads();
-        if (!s_ext) return;
-        // ---- the walk: candidates in selection order from position 1 on
-        const bool mine_in = (uint32_t)tid < n_win;
-        unsigned long long me_cnt = 0ull;
-        uint32_t me_key = 0u, me_rk = 0u;
-        if (mine_in) {
-            me_cnt = s_win[tid].cnt;
-            me_key = s_win[tid].key;
-            me_rk = s_win[tid].rk;
-        }
-        if (mine_in && mypos == 0u) s_acc[0].win = (uint32_t)tid;
-        const unsigned long long candT_all = P.cs->T, min_freq = st->min_freq; // (uniform loads)
-        const uint32_t num_merges = st->num_merges;
-        for (uint32_t pos = 1; pos < n_win; ++pos) {
-            __syncthreads(); // (s_acc / s_nacc of the last round are complete; s_stop was read)
-            const uint32_t nacc = s_nacc;
-            if (nacc >= kmax || s_it + (nacc - 1u) >= num_merges) break;
-            if (tid == 0) s_stop = 0;
-            if (mine_in && mypos == pos) s_cpos = (uint32_t)tid;
-            __syncthreads();
-            const uint32_t cpos = s_cpos;
-            struct { unsigned long long cnt, px, py; uint32_t key, rk, lx, ly; } cj; // (broadcast reads)
-            cj.cnt = s_win[cpos].cnt;
-            cj.key = s_win[cpos].key;
-            cj.rk = s_win[cpos].rk;
-            cj.lx = s_win[cpos].lx;
-            cj.ly = s_win[cpos].ly;
-            cj.px = s_win[cpos].px;
-            cj.py = s_win[cpos].py;
-            const uint32_t p = cj.key >> 16, q = cj.key & 0xffffu;
-            // a second listing of a pair that is in the batch already: nothing to decide
-            bool dup = false;
-            for (uint32_t i = 0; i < nacc; ++i) dup |= s_acc[i].a == p && s_acc[i].b == q;
-            if (dup) continue;
-            if (tid == 0) {
-                bool stop = cj.cnt < candT_all || cj.cnt < min_freq || cj.cnt == 0ull;
-                for (uint32_t i = 0; i < nacc; ++i) stop |= q == s_acc[i].a || p == s_acc[i].b; // rule (1)
-                if (stop) s_stop = 1;
+}
+
+// ---------------------------------------------------------------- the fused selection (tail of every per-batch launch)
+// Same contract as select_body, for a BATCH of merges and built for the critical path: four round trips (list + state, counts, token records
+// of the window, byte-string set probes) and, between them, one workgroup-wide maximum, the window (distinct pairs with
+// count >= max - delta, LDS hash set) and then ONE WAVE that sorts the window, walks it under the batch rule with
+// wave-level votes (no workgroup barriers), probes the byte-string set for every accepted merge side by side and commits.
+// More than WIN pairs tying at the top, or a first merge whose bytes may exist already (a full byte compare decides), end in
+// a batch of one.
+__device__ __forceinline__ void select_eval(const SelectParams &P) {
+    __shared__ WinEnt s_win[WIN];
+    __shared__ AccEnt s_acc[KMAX];
+    __shared__ uint32_t s_hset[2 * WIN];
+    __shared__ unsigned long long s_red[WPB], s_fold[2];
+    __shared__ uint32_t s_nwin;
+    constexpr uint32_t HSET = 2 * WIN;
+    DevState *st = P.st;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    YB_SEL_STAMP(1);
+    // ---- round trip 1: the list's first 4 x BLOCK entries and its length, the DevState fields, the per-workgroup counters
+    unsigned long long e[4], cn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
+    const uint32_t n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
+    const uint32_t kmax = min(st->kmax, (uint32_t)KMAX);
+    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0, d_prev_batch = 0;
+    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0, candT = 0;
+    uint32_t cand_over = 0, cand_n = 0;
+    if (tid == 0) {
+        d_iter = st->iter;
+        d_done = st->done;
+        d_halt = st->halt;
+        d_n_tokens = st->n_tokens;
+        d_pool_used = st->pool_used;
+        d_num_merges = st->num_merges;
+        d_min_freq = st->min_freq;
+        d_live_slots = st->live_slots;
+        d_tokens_now = st->tokens_now;
+        d_prev_batch = st->n_batch;
+        d_halt_req = ld_coherent(&st->halt_req);
+        d_table_entries = ld_coherent(&st->table_entries);
+        d_sites = ld_coherent(&st->sites);
+        candT = P.cs->T;
+        cand_over = ld_coherent(&P.cs->overflow);
+        cand_n = ld_coherent(&P.cs->n);
+        s_fold[0] = 0;
+        s_fold[1] = 0;
+        s_nwin = 0;
+    }
+    unsigned long long vx[4], vy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = k * BLOCK + tid;
+        vx[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i]) : 0ull;
+        vy[k] = i < P.n_blk ? ld_coherent(&P.blk_stats[2 * i + 1]) : 0ull;
+    }
+    for (uint32_t hidx = tid; hidx < HSET; hidx += BLOCK) s_hset[hidx] = EMPTY;
+    // ---- round trip 2: the counts (the slot rides in the list entry)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cn[k] = 0ull;
+        if ((uint32_t)(tid + k * BLOCK) < n_list) cn[k] = ld_coherent(pt_count_ptr(P.table, e[k]));
+    }
+    // (the counters are summed while the counts are on their way)
+    unsigned long long fa = 0, ff = 0;
+    {
+        unsigned long long *bs = P.blk_stats;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * BLOCK + tid;
+            fa += vx[k];
+            ff += vy[k];
+            if (i < P.n_blk && (vx[k] | vy[k])) {
+                bs[2 * i] = 0ull;
+                bs[2 * i + 1] = 0ull;
             }
-            if (mine_in && mypos > pos && me_cnt == cj.cnt) { // rule (2): the pairs that tie with j
-                const uint32_t l = me_key >> 16, r = me_key & 0xffffu;
-                bool in_batch = false, left_new_blocks = false, right_new = false, right_new_ge = false;
+        }
+        for (uint32_t i = 4 * BLOCK + tid; i < P.n_blk; i += BLOCK) { // (grids beyond 1,024 workgroups: the streaming phase)
+            const unsigned long long x = ld_coherent(&bs[2 * i]), y = ld_coherent(&bs[2 * i + 1]);
+            fa += x;
+            ff += y;
+            if (x | y) {
+                bs[2 * i] = 0ull;
+                bs[2 * i + 1] = 0ull;
+            }
+        }
+    }
+    fa = wave_sum_u64(fa);
+    ff = wave_sum_u64(ff);
+    YB_SEL_STAMP(9);
+    unsigned long long cmax = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((long long)cn[k] <= 0) cn[k] = 0ull;
+        cmax = cn[k] > cmax ? cn[k] : cmax;
+    }
+    for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) { // (a long list: rare, the host rebuilds it before)
+        const long long c = (long long)ld_coherent(pt_count_ptr(P.table, ld_coherent(&P.table.cand_list[ti])));
+        if (c > 0 && (unsigned long long)c > cmax) cmax = (unsigned long long)c;
+    }
+    YB_SEL_STAMP(10);
+    cmax = best_wave_reduce(Best{cmax, 0u, 0u, 0u, 0u}).cnt;
+    __syncthreads(); // (s_fold / s_nwin / s_hset initialised)
+    if (lane == 0) {
+        s_red[tid >> 6] = cmax;
+        if (fa | ff) {
+            atomicAdd(&s_fold[0], fa);
+            atomicAdd(&s_fold[1], ff);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) cmax = s_red[w] > cmax ? s_red[w] : cmax;
+    // ---- the window: the DISTINCT pairs with count >= L = cmax - delta (whole count levels by construction; a pair may be
+    // listed more than once, and how often differs between the replicas of a multi-GPU job: the set keeps repeats out, so every
+    // rank walks the same window).  More than WIN of them: a quarter of the distance, again.
+    unsigned long long L = 0ull;
+    uint32_t n_win = 0;
+    if (cmax) {
+        unsigned long long delta = kmax > 1u ? max((unsigned long long)kmax, cmax >> 8) : 0ull;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            L = cmax > delta ? cmax - delta : 1ull;
+            auto put = [&](unsigned long long ent, unsigned long long c) {
+                const uint32_t key = (uint32_t)(ent >> 32);
+                uint32_t h = hash32(key) & (HSET - 1u);
+                for (uint32_t probe = 0; probe < HSET; ++probe) {
+                    const uint32_t was = atomicCAS(&s_hset[h], EMPTY, key);
+                    if (was == key) return; // listed twice
+                    if (was == EMPTY) {
+                        const uint32_t idx = atomicAdd(&s_nwin, 1u);
+                        if (idx < (uint32_t)WIN) {
+                            s_win[idx].cnt = c;
+                            s_win[idx].key = key;
+                            s_win[idx].slot = (uint32_t)ent;
+                        }
+                        return;
+                    }
+                    h = (h + 1u) & (HSET - 1u);
+                }
+                s_nwin = WIN + 1u; // (the set is full: more distinct pairs than a window holds)
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cn[k] >= L) put(e[k], cn[k]);
+            for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) {
+                const unsigned long long ent = ld_coherent(&P.table.cand_list[ti]);
+                const long long c = (long long)ld_coherent(pt_count_ptr(P.table, ent));
+                if (c > 0 && (unsigned long long)c >= L) put(ent, (unsigned long long)c);
+            }
+            __syncthreads();
+            n_win = s_nwin;
+            if (n_win <= (uint32_t)WIN) break;
+            n_win = 0;
+            if (delta == 0ull) break; // more than WIN pairs tie at the top: no window
+            delta >>= 2;
+            __syncthreads(); // (everybody has read s_nwin)
+            for (uint32_t hidx = tid; hidx < HSET; hidx += BLOCK) s_hset[hidx] = EMPTY;
+            if (tid == 0) s_nwin = 0;
+            __syncthreads();
+        }
+    }
+    if (cmax && n_win == 0) {
+        // More than WIN distinct pairs tie at the top (small counts late in a small job): no walk -- the greatest of them by
+        // (lexrank, lexrank) is the merge (trainer.py:246), found the plain way; it becomes a window of one.
+        __shared__ Best s_tb[WPB];
+        Best tb{0ull, 0u, EMPTY, 0u, 0u};
+        auto consider = [&](unsigned long long ent) {
+            const uint32_t key = (uint32_t)(ent >> 32);
+            const uint32_t rl = (uint32_t)ld_coherent(reinterpret_cast<const unsigned long long *>(&P.tt.rec[key >> 16]));
+            const uint32_t rr = (uint32_t)ld_coherent(reinterpret_cast<const unsigned long long *>(&P.tt.rec[key & 0xffffu]));
+            const Best b{1ull, (rl << 16) | rr, key, (uint32_t)ent, 0u};
+            if (best_gt(b, tb)) tb = b;
+        };
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k)
+            if (cn[k] == cmax) consider(e[k]);
+        for (uint32_t ti = 4u * BLOCK + tid; ti < n_list; ti += BLOCK) {
+            const unsigned long long ent = ld_coherent(&P.table.cand_list[ti]);
+            if (ld_coherent(pt_count_ptr(P.table, ent)) == cmax) consider(ent);
+        }
+        tb = best_wave_reduce(tb);
+        __syncthreads(); // (the last read of s_nwin is behind everybody)
+        if (lane == 0) s_tb[tid >> 6] = tb;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < WPB; ++w)
+                if (best_gt(s_tb[w], tb)) tb = s_tb[w];
+            s_win[0].cnt = cmax;
+            s_win[0].key = tb.key;
+            s_win[0].slot = tb.slot;
+        }
+        __syncthreads();
+        n_win = 1;
+    }
+    // ---- round trip 3: the two token records of every window entry (one entry per thread)
+    if ((uint32_t)tid < n_win) {
+        const uint32_t key = s_win[tid].key;
+        const unsigned long long *qx = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key >> 16]);
+        const unsigned long long *qy = reinterpret_cast<const unsigned long long *>(&P.tt.rec[key & 0xffffu]);
+        const unsigned long long ax = ld_coherent(qx), hx = ld_coherent(qx + 1), px = ld_coherent(qx + 2);
+        const unsigned long long ay = ld_coherent(qy), hy = ld_coherent(qy + 1), py = ld_coherent(qy + 2);
+        s_win[tid].rk = ((uint32_t)ax << 16) | ((uint32_t)ay & 0xffffu);
+        s_win[tid].lx = (uint32_t)(ax >> 32);
+        s_win[tid].ly = (uint32_t)(ay >> 32);
+        s_win[tid].hx = hx;
+        s_win[tid].hy = hy;
+        s_win[tid].px = px;
+        s_win[tid].py = py;
+    }
+    __syncthreads();
+    YB_SEL_STAMP(11);
+    if (tid >= 64) return; // ---- from here on: wave 0 alone, wave-level synchronisation only
+    // selection order by counting (two entries per lane): an entry's position is the number of entries in front of it
+    unsigned long long mc[2] = {0ull, 0ull};
+    uint32_t mkey[2] = {0u, 0u}, mrk[2] = {0u, 0u}, mpos[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t idx = (uint32_t)lane + 64u * h;
+        if (idx < n_win) {
+            mc[h] = s_win[idx].cnt;
+            mkey[h] = s_win[idx].key;
+            mrk[h] = s_win[idx].rk;
+            mpos[h] = 0;
+        }
+    }
+    for (uint32_t u = 0; u < n_win; ++u) {
+        const unsigned long long cu = s_win[u].cnt;
+        const uint32_t ru = s_win[u].rk;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (mpos[h] != 0xffffffffu) mpos[h] += (cu > mc[h]) || (cu == mc[h] && ru > mrk[h]); // (distinct pairs: (count, ranks) never tie)
+    }
+    // window index of the entry at position `pos` (wave-uniform), or WIN
+    auto at_pos = [&](uint32_t pos) -> uint32_t {
+        const unsigned long long b0 = __ballot(mpos[0] == pos), b1 = __ballot(mpos[1] == pos);
+        return b0 ? (uint32_t)(__ffsll((long long)b0) - 1) : b1 ? 64u + (uint32_t)(__ffsll((long long)b1) - 1) : (uint32_t)WIN;
+    };
+    // ---- stop rules and the first merge (lane 0 holds the state)
+    uint32_t flag = 0; // 1: nothing selected (done / halt)
+    const uint32_t w0 = cmax ? at_pos(0) : (uint32_t)WIN;
+    const unsigned long long best_cnt = w0 < (uint32_t)WIN ? s_win[w0].cnt : 0ull;
+    if (lane == 0) {
+        if (d_halt == 0 && d_halt_req != 0) d_halt = d_halt_req;
+        if (P.delta_hdr) { // this rank's send header for the next exchange
+            P.delta_hdr->count = 0ull;
+            P.delta_hdr->halt = d_halt;
+        }
+        if (d_halt == 0 && d_table_entries * 5ull > (unsigned long long)P.table.cap * 4ull) d_halt = HALT_TABLE_FULL; // > 80 % full (the same on every rank)
+        d_sites += s_fold[0];
+        d_live_slots -= s_fold[1];
+        if (d_done | d_halt) {
+            flag = 1;
+        } else {
+            // close the log entries of the batch that has just been applied (see select_body)
+            const uint32_t it = d_iter;
+            if (it > P.rec_base && d_sites) {
+                const uint32_t pb = min(max(d_prev_batch, 1u), it - P.rec_base);
+                unsigned long long others = 0;
+                if (P.flat_single)
+                    for (uint32_t m = it - pb; m + 1 < it; ++m) others += P.rec_count[m - P.rec_base];
+                if (others <= d_sites && P.flat_single) {
+                    for (uint32_t m = it - pb; m + 1 < it; ++m) P.rec_sites[m - P.rec_base] = P.rec_count[m - P.rec_base];
+                    P.rec_sites[it - 1 - P.rec_base] = d_sites - others;
+                } else {
+                    P.rec_sites[it - 1 - P.rec_base] = d_sites;
+                }
+            }
+            d_tokens_now -= d_sites;
+            d_sites = 0;
+            if (it < d_num_merges && (best_cnt < candT || cand_over)) {
+                d_halt = HALT_RESCAN; // the candidate set no longer proves the maximum: the host redoes this merge with a full scan
+                flag = 1;
+            } else if (it >= d_num_merges || best_cnt == 0 || best_cnt < d_min_freq) {
+                d_done = 1; // stop rules: iteration limit (trainer.py:241), no pairs (:242-243), min_frequency (:247-248)
+                flag = 1;
+            }
+        }
+        st->halt = d_halt;
+        st->done = d_done;
+        st->sites = d_sites;
+        st->live_slots = d_live_slots;
+        st->tokens_now = d_tokens_now;
+        st->cand_n = cand_n;
+        if (flag) st->n_batch = 0u;
+    }
+    flag = __builtin_amdgcn_readfirstlane(flag);
+    if (flag) return;
+    YB_SEL_STAMP(3);
+    // ---- the walk (see the batch rule above select_body): positions 0, 1, ... of the window
+    const uint32_t it0 = __builtin_amdgcn_readfirstlane(d_iter), num_merges = __builtin_amdgcn_readfirstlane(d_num_merges);
+    const unsigned long long T_all = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(candT >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)candT);
+    const unsigned long long minf = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(d_min_freq >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d_min_freq);
+    uint32_t nacc = 0;
+    for (uint32_t pos = 0; pos < n_win && nacc < kmax && it0 + nacc < num_merges; ++pos) {
+        const uint32_t ci = at_pos(pos);
+        if (ci >= (uint32_t)WIN) break;
+        const unsigned long long c_cnt = s_win[ci].cnt;
+        const uint32_t c_key = s_win[ci].key, c_rk = s_win[ci].rk, c_lx = s_win[ci].lx, c_ly = s_win[ci].ly;
+        const unsigned long long c_px = s_win[ci].px, c_py = s_win[ci].py;
+        const uint32_t p = c_key >> 16, q = c_key & 0xffffu;
+        if (nacc) {
+            bool stop = c_cnt < T_all || c_cnt < minf || c_cnt == 0ull;
+            for (uint32_t i = 0; i < nacc; ++i) stop |= q == s_acc[i].a || p == s_acc[i].b; // rule (1)
+            // rule (2): the pairs that tie with the candidate and come after it
+            bool blocks = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (mpos[h] == 0xffffffffu || mpos[h] <= pos || mc[h] != c_cnt) continue;
+                const uint32_t l = mkey[h] >> 16, r = mkey[h] & 0xffffu;
+                bool left_new_blocks = false, right_new = false, right_new_ge = false;
                 for (uint32_t i = 0; i < nacc; ++i) {
                     const AccEnt A = s_acc[i];
-                    in_batch |= A.a == l && A.b == r;
-                    if (A.b == l) left_new_blocks |= cmp_pre8(A.pc, A.lc, cj.px, cj.lx) != -1; // (c_i, .) vs (p, .)
+                    if (A.b == l) left_new_blocks |= cmp_pre8(A.pc, A.lc, c_px, c_lx) != -1; // (c_i, .) against (p, .)
                     if (A.a == r) {
                         right_new = true;
-                        const int cr = cmp_pre8(A.pc, A.lc, cj.py, cj.ly); // (., c_i) vs (., q)
-                        right_new_ge |= cr != -1;
+                        right_new_ge |= cmp_pre8(A.pc, A.lc, c_py, c_ly) != -1; // (., c_i) against (., q)
                     }
                 }
-                const uint32_t rl = me_rk >> 16, rp = cj.rk >> 16; // lexranks of l and p
-                const bool blocks = left_new_blocks || (right_new && (rl > rp || (rl == rp && right_new_ge)));
-                if (!in_batch && blocks) s_stop = 1; // (benign race: every writer stores 1)
+                const uint32_t rl = mrk[h] >> 16, rp = c_rk >> 16; // lexranks of l and p
+                blocks |= left_new_blocks || (right_new && (rl > rp || (rl == rp && right_new_ge)));
             }
-            __syncthreads();
-            if (s_stop) break;
-            if (tid == 0) {
-                s_acc[nacc] = AccEnt{p, q, cj.lx + cj.ly, cpos, pre8_concat(cj.px, cj.lx, cj.py)};
-                s_nacc = nacc + 1u;
-            }
-            if (p == q) { // rule (3): a run merge closes the batch
-                __syncthreads();
-                break;
-            }
+            if (stop || __any(blocks)) break;
         }
-        __syncthreads();
-        uint32_t nacc = s_nacc;
-        if (nacc <= 1u) return;
-        // ---- the merged tokens of merges 1 .. nacc-1: one probe of the byte-string set each, side by side
-        if (tid >= 1 && (uint32_t)tid < nacc) {
-            const WinEnt w = s_win[s_acc[tid].win];
-            const uint32_t Lk = w.lx + w.ly;
-            const unsigned long long Hk = yb_hash_concat(w.hx, w.hy, w.ly);
-            uint32_t slot = yb_vset_home(Hk, Lk) & P.tt.vset_mask;
-            unsigned long long ve = ld_coherent(&P.tt.vset[slot]);
-            while (ve != VSET_EMPTY && (ve >> 32) != (Hk >> 32)) {
-                slot = (slot + 1) & P.tt.vset_mask;
-                ve = ld_coherent(&P.tt.vset[slot]);
-            }
-            s_pslot[tid] = slot;
-            s_phit[tid] = ve != VSET_EMPTY; // same 32 hash bits as an existing token: that merge opens the next batch (full compare there)
-            s_pH[tid] = Hk;
-            s_pL[tid] = Lk;
+        if (lane == 0) s_acc[nacc] = AccEnt{p, q, c_lx + c_ly, ci, pre8_concat(c_px, c_lx, c_py)};
+        wave_sync();
+        ++nacc;
+        if (p == q) break; // rule (3): a run merge closes the batch
+    }
+    // ---- round trip 4: the merged tokens: one probe of the byte-string set each, side by side (lane k: merge k)
+    unsigned long long Hk = 0ull, ve = VSET_EMPTY;
+    uint32_t Lk = 0, vslot = 0, wk = 0;
+    if ((uint32_t)lane < nacc) {
+        wk = s_acc[lane].win;
+        const uint32_t lxk = s_win[wk].lx, lyk = s_win[wk].ly;
+        Lk = lxk + lyk;
+        Hk = yb_hash_concat(s_win[wk].hx, s_win[wk].hy, lyk);
+        vslot = yb_vset_home(Hk, Lk) & P.tt.vset_mask;
+        ve = ld_coherent(&P.tt.vset[vslot]);
+        while (ve != VSET_EMPTY && (ve >> 32) != (Hk >> 32)) {
+            vslot = (vslot + 1) & P.tt.vset_mask;
+            ve = ld_coherent(&P.tt.vset[vslot]);
         }
-        __syncthreads();
-        if (tid == 0) { // the batch ends in front of the first merge whose token cannot be created blindly
-            uint32_t keep = 1;
-            unsigned long long pool_at = s_pool;
-            for (uint32_t k = 1; k < nacc; ++k) {
-                bool bad = s_phit[k] != 0u || s_ntok + (k - 1u) >= YB_MAX_TOKENS || pool_at + s_pL[k] + 4ull > P.tt.pool_cap;
-                for (uint32_t k2 = 0; k2 < k; ++k2) bad |= s_pslot[k2] == s_pslot[k] || (s_pH[k2] == s_pH[k] && s_pL[k2] == s_pL[k]);
-                if (bad) break;
-                pool_at = (pool_at + s_pL[k] + 3ull) & ~3ull;
-                keep = k + 1u;
-            }
-            s_nacc = keep;
+    }
+    YB_SEL_STAMP(5);
+    const bool hit = (uint32_t)lane < nacc && ve != VSET_EMPTY; // same 32 hash bits as an existing token: a full compare decides
+    // the batch ends in front of the first later merge whose token cannot be created blindly: possible hit, the same slot or the
+    // same (hash, length) as an earlier merge of the batch, no id or no pool space left
+    uint32_t bad = hit ? 1u : 0u;
+    for (uint32_t k2 = 0; k2 + 1 < nacc; ++k2) {
+        const uint32_t s2 = __builtin_amdgcn_readlane(vslot, k2), l2 = __builtin_amdgcn_readlane(Lk, k2);
+        const unsigned long long h2 = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(Hk >> 32), k2) << 32) | __builtin_amdgcn_readlane((uint32_t)Hk, k2);
+        if ((uint32_t)lane < nacc && (uint32_t)lane > k2 && (s2 == vslot || (h2 == Hk && l2 == Lk))) bad = 1u;
+    }
+    // pool offsets: exclusive prefix of the 4-byte-rounded lengths (a handful of lanes)
+    const uint32_t ntok0 = __builtin_amdgcn_readfirstlane(d_n_tokens), pool0 = __builtin_amdgcn_readfirstlane(d_pool_used);
+    uint32_t pool_at = pool0;
+    for (uint32_t k2 = 0; k2 + 1 < nacc; ++k2) {
+        const uint32_t l2 = __builtin_amdgcn_readlane(Lk, k2);
+        if ((uint32_t)lane > k2) pool_at += (l2 + 3u) & ~3u;
+    }
+    if ((uint32_t)lane < nacc && (ntok0 + (uint32_t)lane >= YB_MAX_TOKENS || (unsigned long long)pool_at + Lk + 4ull > P.tt.pool_cap)) bad = 1u;
+    const unsigned long long badm = __ballot(bad != 0u);
+    const uint32_t keep = badm ? (uint32_t)(__ffsll((long long)badm) - 1) : nacc; // merges [0, keep) are committed here
+    if ((uint32_t)lane < keep) { // commit merge k = lane
+        const uint32_t k = (uint32_t)lane;
+        const uint32_t cid = ntok0 + k, key = s_win[wk].key;
+        P.tt.off[cid] = pool_at;
+        P.tt.len[cid] = Lk;
+        P.tt.rec[cid] = TokRec{0u, Lk, Hk, s_acc[k].pc, 0ull};
+        P.tt.vset[vslot] = yb_vset_entry(cid, Hk);
+        const uint32_t ri = it0 - P.rec_base + k;
+        P.rec_left[ri] = key >> 16; // merges.append(best_pair) (trainer.py:296)
+        P.rec_right[ri] = key & 0xffffu;
+        P.rec_merged[ri] = cid;
+        P.rec_count[ri] = s_win[wk].cnt;
+        P.rec_live_slots[ri] = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(d_live_slots >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d_live_slots);
+        // after the merge no (x, y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0: set it here once
+        // instead of letting every workgroup subtract its share from one hot address
+        P.table.cnt[s_win[wk].slot] = 0ull;
+        st->batch[k] = BatchMerge{key >> 16, key & 0xffffu, cid, 1u};
+        if (k == 0u) {
+            st->a = key >> 16;
+            st->b = key & 0xffffu;
+            st->c = cid;
+            st->c_is_new = 1u;
         }
-        __syncthreads();
-        nacc = s_nacc;
-        if (nacc <= 1u) return;
-        if (tid >= 1 && (uint32_t)tid < nacc) { // commit merge k = tid
-            const uint32_t k = (uint32_t)tid;
-            const WinEnt w = s_win[s_acc[k].win];
-            uint32_t pool_at = s_pool;
-            for (uint32_t k2 = 1; k2 < k; ++k2) pool_at = (pool_at + s_pL[k2] + 3u) & ~3u;
-            const uint32_t cid = s_ntok + (k - 1u);
-            P.tt.off[cid] = pool_at;
-            P.tt.len[cid] = s_pL[k];
-            P.tt.rec[cid] = TokRec{0u, s_pL[k], s_pH[k], s_acc[k].pc, 0ull};
-            P.tt.vset[s_pslot[k]] = yb_vset_entry(cid, s_pH[k]);
-            const uint32_t ri = s_it - P.rec_base + (k - 1u);
-            P.rec_left[ri] = w.key >> 16;
-            P.rec_right[ri] = w.key & 0xffffu;
-            P.rec_merged[ri] = cid;
-            P.rec_count[ri] = w.cnt;
-            P.rec_live_slots[ri] = st->live_slots;
-            P.table.cnt[w.slot] = 0ull;
-            st->batch[k] = BatchMerge{w.key >> 16, w.key & 0xffffu, cid, 1u};
-            if (k == nacc - 1u) {
-                uint32_t pool_end = (pool_at + s_pL[k] + 3u) & ~3u;
-                st->pool_used = pool_end;
-                st->n_tokens = cid + 1u;
-                st->iter = s_it + (nacc - 1u);
-                st->n_batch = nacc;
-                st->best_count = w.cnt; // (the host's heuristics look at the lowest count selected so far)
+        if (k + 1u == keep) {
+            st->pool_used = (pool_at + Lk + 3u) & ~3u;
+            st->n_tokens = cid + 1u;
+            st->iter = it0 + keep;
+            st->n_batch = keep;
+            st->best_count = s_win[wk].cnt; // (the host's heuristics look at the lowest count selected so far)
+#ifdef YB_PROFILE_LAUNCH
+            g_launch_prof[(it0 & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
+#endif
+        }
+    }
+    YB_SEL_STAMP(7);
+    if (keep != 0u) return;
+    // ---- the first merge could not be created blindly: its bytes may be a token already (trainer.py:298-300: then it keeps
+    // that id), or there is no id / no pool space left.  Settled here by the whole wave, one merge, the batch ends with it.
+    {
+        const uint32_t w = s_acc[0].win;
+        const uint32_t key = s_win[w].key, x = key >> 16, y = key & 0xffffu, lx = s_win[w].lx, Lm = lx + s_win[w].ly;
+        const unsigned long long Hm = yb_hash_concat(s_win[w].hx, s_win[w].hy, s_win[w].ly);
+        uint32_t slot = yb_vset_home(Hm, Lm) & P.tt.vset_mask, found = EMPTY;
+        while (true) { // (every lane walks the same slots)
+            const unsigned long long en = ld_coherent(&P.tt.vset[slot]);
+            if (en == VSET_EMPTY) break;
+            if ((en >> 32) == (Hm >> 32)) {
+                const uint32_t cand = (uint32_t)en;
+                const TokRec rc = P.tt.rec[cand];
+                if (rc.len == Lm && rc.hash == Hm) {
+                    const uint32_t oc = P.tt.off[cand], ox = P.tt.off[x], oy = P.tt.off[y];
+                    bool ne = false;
+                    for (uint32_t i = (uint32_t)lane; i < Lm; i += 64u)
+                        ne |= pool_byte_coherent(P.tt.pool, oc + i) != pool_byte_coherent(P.tt.pool, i < lx ? ox + i : oy + (i - lx));
+                    if (!__any(ne)) {
+                        found = cand;
+                        break;
+                    }
+                }
+            }
+            slot = (slot + 1) & P.tt.vset_mask;
+        }
+        if (lane == 0) {
+            uint32_t cid = 0, is_new = 0;
+            bool ok = true;
+            if (found != EMPTY) {
+                cid = found; // bytes already a token: no id is consumed
+            } else if (ntok0 >= YB_MAX_TOKENS) {
+                st->halt = HALT_VOCAB_FULL;
+                ok = false;
+            } else if ((unsigned long long)pool0 + Lm + 4ull > P.tt.pool_cap) {
+                st->halt = HALT_POOL_FULL;
+                ok = false;
+            } else {
+                cid = ntok0;
+                P.tt.off[cid] = pool0;
+                P.tt.len[cid] = Lm;
+                P.tt.rec[cid] = TokRec{0u, Lm, Hm, s_acc[0].pc, 0ull};
+                P.tt.vset[slot] = yb_vset_entry(cid, Hm);
+                is_new = 1;
+            }
+            if (!ok) {
+                st->n_batch = 0u;
+            } else {
+                const uint32_t ri = it0 - P.rec_base;
+                P.rec_left[ri] = x;
+                P.rec_right[ri] = y;
+                P.rec_merged[ri] = cid;
+                P.rec_count[ri] = s_win[w].cnt;
+                P.rec_live_slots[ri] = d_live_slots;
+                P.table.cnt[s_win[w].slot] = 0ull;
+                st->a = x;
+                st->b = y;
+                st->c = cid;
+                st->c_is_new = is_new;
+                st->best_count = s_win[w].cnt;
+                st->batch[0] = BatchMerge{x, y, cid, is_new};
+                st->n_batch = 1u;
+                st->iter = it0 + 1u;
+                st->pool_used = is_new ? ((pool0 + Lm + 3u) & ~3u) : pool0;
+                st->n_tokens = ntok0 + is_new;
+#ifdef YB_PROFILE_LAUNCH
+                g_launch_prof[(it0 & 0xFFFFu) * 4 + 3] = wall_clock64();
+#endif
             }
         }
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body<false>(P, best_ex_none()); }
+
+__global__ __launch_bounds__(BLOCK) void k_select(SelectParams P) { select_body(P); }
 
 // ================================================================ loading words into tiles
 struct LoadParams {
@@ -2575,7 +2705,7 @@ __device__ __forceinline__ void fused_select_tail(const FuseParams &F) {
     if (!last_workgroup(F.ticket)) return;
     if (threadIdx.x >= BLOCK) return; // (a wider workgroup: the selection is written for BLOCK threads; ended waves are not waited for)
     YB_SEL_STAMP(8);
-    select_body<true>(F.sel, best_ex_none());
+    select_eval(F.sel);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
@@ -2605,7 +2735,7 @@ __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
     // the selection reads from THIS kernel -- the partials -- goes through device-scope accesses; each workgroup waits
     // for its own to be acknowledged before it takes its ticket.
     if (!last_workgroup(P.ticket)) return;
-    select_body<false>(P.sel, best_ex_none());
+    select_body(P.sel);
 }
 
 // list = every slot with count >= cs->T (the bitmap was cleared by the host)
@@ -3034,6 +3164,7 @@ __global__ __launch_bounds__(BLOCK) void k_records_apply(RecApplyParams P) {
 struct CmpParams {
     PairTable ta, tb;
     unsigned long long *mismatches;
+    unsigned long long *dump; // may be NULL
 };
 
 __device__ __forceinline__ long long gt_lookup(const PairTable &t, uint32_t key) {
@@ -3052,7 +3183,15 @@ __global__ __launch_bounds__(BLOCK) void k_table_compare(CmpParams P) {
     for (uint32_t s = blockIdx.x * BLOCK + threadIdx.x; s < cap; s += gridDim.x * BLOCK) {
         uint32_t k = P.ta.keys[s];
         if (k == EMPTY) continue;
-        if ((long long)P.ta.cnt[s] != gt_lookup(P.tb, k)) atomicAdd(P.mismatches, 1ull);
+        const long long va = (long long)P.ta.cnt[s], vb = gt_lookup(P.tb, k);
+        if (va != vb) {
+            const unsigned long long idx = atomicAdd(P.mismatches, 1ull);
+            if (P.dump && idx < 16ull) { // (diagnostics: the first few differing keys with both counts)
+                P.dump[3 * idx] = k;
+                P.dump[3 * idx + 1] = (unsigned long long)va;
+                P.dump[3 * idx + 2] = (unsigned long long)vb;
+            }
+        }
     }
 }
 
