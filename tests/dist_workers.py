@@ -210,3 +210,30 @@ def gpu_text_sharded(rank, world, dist, path, chunk_size, vocab_size, specials):
     cfg = BBPETrainerConfig(vocab_size=vocab_size, min_frequency=1, special_tokens=specials, chunk_size_bytes=chunk_size)
     model = train_text_sharded(lambda: _native.Context(0), [path], cfg, rank, world, transport="torch", options={"verify": 1})
     return [(a.hex(), b.hex()) for a, b in model.merges], len(model.vocab)
+
+
+def gpu_fullsize_sharded(rank, world, dist):
+    """BASELINE configs[3]: the 1 GiB / 32,000-merge job word-sharded over `world` ranks that share the test box's one GPU
+    (custom transport, gloo underneath).  Every rank generates the corpus on the device, trains on its word range and
+    returns the digest of its (left, right, merged) id triples, its merge count and the corpus digest inputs."""
+    import hashlib
+
+    import numpy as np
+
+    from tests import helpers
+    from yet_another_bpe import _native, synth
+    from yet_another_bpe.distributed import ShardedRunner
+
+    spec = synth.SynthSpec.config3(1024 << 20)
+    base = helpers.base_tokens(["<|endoftext|>"])
+    with _native.Context(0) as gen:
+        pb, po, nw, nb = gen.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
+        runner = ShardedRunner(gen, pb, po, nw, nb, base, rank, world, 0, transport="torch")
+        try:
+            res = runner.run(32000, 1)
+            mism = runner._ctx.verify_table()
+        finally:
+            runner.close()
+    h = hashlib.sha256(res["left"].astype(np.uint32).tobytes() + res["right"].astype(np.uint32).tobytes() + res["merged"].astype(np.uint32).tobytes()).hexdigest()
+    st = res["stats"]
+    return h, int(res["n_merges"]), int(nw), int(nb), int(mism), int(st["n_words"]), int(st["exchanges"]), int(st["exchange_growths"])

@@ -27,7 +27,15 @@ with _native.Context() as g:
               % (rel(8), rel(9), rel(10), rel(11), rel(2), rel(3), rel(4), rel(5), rel(6), rel(7)))
         out = np.zeros(65536 * 4, dtype=np.uint64)
         L.yabpe_debug_launch_profile(ctypes.c_void_p(out.ctypes.data), 0)
+        sh = np.zeros(65536, dtype=np.uint64)
+        L.yabpe_debug_stop_hist(ctypes.c_void_p(sh.ctypes.data))
 raw = out.reshape(65536, 4)
+names = {0: "-", 1: "rule 1 (token consumed)", 2: "rule 2 (tie may come first)", 3: "below list threshold", 4: "limit", 5: "window end", 6: "run merge"}
+for lo, hi in [(80, 300), (300, 1000), (1000, 3000), (3000, 12000), (12000, 32000)]:
+    v = sh[lo:hi]; v = v[v != 0]
+    if len(v) == 0: continue
+    why = (v & np.uint64(0xff)).astype(int); n = ((v >> np.uint64(8)) & np.uint64(0xff)).astype(int); nw = (v >> np.uint64(16)).astype(int)
+    print(f"selections at merges {lo}-{hi}: {len(v)}  mean batch {n.mean():.2f}  window entries mean {nw.mean():.1f} max {nw.max()} | ended by: " + ", ".join(f"{names.get(k, k)} {np.mean(why == k) * 100:.0f}%" for k in sorted(set(why))))
 p = raw.astype(np.float64) / 100.0  # us
 valid = np.nonzero((raw[:, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)) & (raw[:, 1] != 0) & (raw[:, 3] != 0))[0]  # row = DevState::iter when the launch started
 nxt = valid[1:]

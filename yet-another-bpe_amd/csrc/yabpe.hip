@@ -1387,6 +1387,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     h->halt_req = 0;
     h->n_batch = 0;
     h->kmax = 1;
+    h->win_shift = 3;
     TRY(state_push(c));
     c->kmax_now = 1;
     c->rec_n = 0;
@@ -1945,6 +1946,9 @@ int yabpe_debug_launch_profile(unsigned long long *out, int reset) { // 65536 x 
         return hipMemcpyToSymbol(HIP_SYMBOL(yb::g_launch_prof), z.data(), z.size() * 8) == hipSuccess ? 0 : -1;
     }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_launch_prof), (size_t)65536 * 32) == hipSuccess ? 0 : -1;
+}
+int yabpe_debug_stop_hist(unsigned long long *out) { // 65536 x u64
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_stop_hist), (size_t)65536 * 8) == hipSuccess ? 0 : -1;
 }
 int yabpe_debug_scan_profile(unsigned long long *out, uint32_t n_blocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_scan_prof), (size_t)std::min<uint32_t>(n_blocks, yb::MAX_LISTS_PROF) * 64) == hipSuccess ? 0 : -1;

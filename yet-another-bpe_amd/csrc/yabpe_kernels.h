@@ -68,6 +68,9 @@ struct DevState {
     unsigned long long best_count; // count of the merge being applied
     uint32_t xmax;                 // multi-GPU: the largest record count any rank has sent since the host cleared this (k_delta_apply)
     uint32_t kmax;                 // merges the next selection may put in one batch (1: the streaming form applies one merge per launch)
+    uint32_t win_shift;            // the selection's window takes the pairs with count >= max - (max >> win_shift); it adapts the shift to
+                                   // what it finds (few pairs: wider, more than fit: narrower) -- from counts and distinct pairs only, so
+                                   // every rank of a multi-GPU job keeps the same value
     uint32_t n_batch;              // merges selected and not applied yet: batch[0 .. n_batch), in selection order; a, b, c above = batch[0]
     BatchMerge batch[KMAX];
 };
@@ -1739,11 +1742,14 @@ __global__ __launch_bounds__(BLOCK) void k_fold_stats(FoldParams P) { fold_block
 
 
 #ifdef YB_PROFILE_SCAN
+__device__ unsigned long long g_stop_hist[65536]; // per selection (index: DevState::iter when it ran): why the batch ended | batch size << 8 | window entries << 16
+#define YB_STOP(it, why, n, nw) do { if (lane == 0) g_stop_hist[(it) & 0xFFFFu] = (unsigned long long)(why) | ((unsigned long long)(n) << 8) | ((unsigned long long)(nw) << 16); } while (0)
 __device__ unsigned long long g_launch_prof[65536 * 4]; // per merge: min start, max end of the workgroups, -, selection end
 __device__ unsigned long long g_sel_prof[16];
 #define YB_SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_prof[i] = wall_clock64(); } while (0)
 #else
 #define YB_SEL_STAMP(i) do { } while (0)
+#define YB_STOP(it, why, n, nw) do { } while (0)
 #endif
 // What a thread knows about its best candidate: the argmax record plus the two tokens' (len, hash), so that the winner's
 // merged token needs no further trip to the token table.
@@ -2190,9 +2196,10 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     // rank walks the same window).  More than WIN of them: a quarter of the distance, again.
     unsigned long long L = 0ull;
     uint32_t n_win = 0;
+    uint32_t wshift = min(max(st->win_shift, 2u), 20u), narrowed = 0;
     if (cmax) {
-        unsigned long long delta = kmax > 1u ? max((unsigned long long)kmax, cmax >> 8) : 0ull;
-        for (int attempt = 0; attempt < 4; ++attempt) {
+        unsigned long long delta = kmax > 1u ? max((unsigned long long)kmax, cmax >> wshift) : 0ull;
+        for (int attempt = 0; attempt < 8; ++attempt) {
             L = cmax > delta ? cmax - delta : 1ull;
             auto put = [&](unsigned long long ent, unsigned long long c) {
                 const uint32_t key = (uint32_t)(ent >> 32);
@@ -2227,6 +2234,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
             n_win = 0;
             if (delta == 0ull) break; // more than WIN pairs tie at the top: no window
             delta >>= 2;
+            narrowed += 2;
             __syncthreads(); // (everybody has read s_nwin)
             for (uint32_t hidx = tid; hidx < HSET; hidx += BLOCK) s_hset[hidx] = EMPTY;
             if (tid == 0) s_nwin = 0;
@@ -2284,9 +2292,11 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     __syncthreads();
     YB_SEL_STAMP(11);
     if (tid >= 64) return; // ---- from here on: wave 0 alone, wave-level synchronisation only
-    // selection order by counting (two entries per lane): an entry's position is the number of entries in front of it
+    // A lane keeps two window entries in registers: count, key, lexranks, and two bit sets over the merges accepted so far --
+    // ra: bit i = "my right token is a_i", lb: bit i = "my left token is b_i" (what rules (1) and (2) ask about).
     unsigned long long mc[2] = {0ull, 0ull};
-    uint32_t mkey[2] = {0u, 0u}, mrk[2] = {0u, 0u}, mpos[2] = {0xffffffffu, 0xffffffffu};
+    uint32_t mkey[2] = {0u, 0u}, mrk[2] = {0u, 0u}, mra[2] = {0u, 0u}, mlb[2] = {0u, 0u};
+    bool mlive[2] = {false, false}; // in the window and not walked yet
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t idx = (uint32_t)lane + 64u * h;
@@ -2294,25 +2304,35 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
             mc[h] = s_win[idx].cnt;
             mkey[h] = s_win[idx].key;
             mrk[h] = s_win[idx].rk;
-            mpos[h] = 0;
+            mlive[h] = true;
         }
     }
-    for (uint32_t u = 0; u < n_win; ++u) {
-        const unsigned long long cu = s_win[u].cnt;
-        const uint32_t ru = s_win[u].rk;
+    // the next entry in selection order: the maximum by (count, lexranks) of what has not been walked (distinct pairs: no ties)
+    struct Cand { unsigned long long cnt; uint32_t rk, key, win, ralb; };
+    auto next_cand = [&]() -> Cand {
+        Best loc{0ull, 0u, EMPTY, 0u, 0u};
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (mpos[h] != 0xffffffffu) mpos[h] += (cu > mc[h]) || (cu == mc[h] && ru > mrk[h]); // (distinct pairs: (count, ranks) never tie)
-    }
-    // window index of the entry at position `pos` (wave-uniform), or WIN
-    auto at_pos = [&](uint32_t pos) -> uint32_t {
-        const unsigned long long b0 = __ballot(mpos[0] == pos), b1 = __ballot(mpos[1] == pos);
-        return b0 ? (uint32_t)(__ffsll((long long)b0) - 1) : b1 ? 64u + (uint32_t)(__ffsll((long long)b1) - 1) : (uint32_t)WIN;
+        for (int h = 0; h < 2; ++h) {
+            const Best b{mlive[h] ? mc[h] : 0ull, mrk[h], mkey[h], (uint32_t)lane + 64u * h, 0u};
+            if (mlive[h] && best_gt(b, loc)) loc = b;
+        }
+        const Best w = best_wave_reduce(loc); // (.slot carries the window index)
+        uint32_t ralb = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool me = w.cnt != 0ull && w.slot == (uint32_t)lane + 64u * h;
+            if (me) {
+                mlive[h] = false;
+                ralb = mra[h] | mlb[h];
+            }
+        }
+        const unsigned long long own = __ballot(ralb != 0u);
+        return Cand{w.cnt, w.rk, w.key, w.slot, own ? 1u : 0u};
     };
     // ---- stop rules and the first merge (lane 0 holds the state)
     uint32_t flag = 0; // 1: nothing selected (done / halt)
-    const uint32_t w0 = cmax ? at_pos(0) : (uint32_t)WIN;
-    const unsigned long long best_cnt = w0 < (uint32_t)WIN ? s_win[w0].cnt : 0ull;
+    Cand cj = next_cand();
+    const unsigned long long best_cnt = cj.cnt;
     if (lane == 0) {
         if (d_halt == 0 && d_halt_req != 0) d_halt = d_halt_req;
         if (P.delta_hdr) { // this rank's send header for the next exchange
@@ -2356,50 +2376,78 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         st->tokens_now = d_tokens_now;
         st->cand_n = cand_n;
         if (flag) st->n_batch = 0u;
+        // next time: a narrower window after an overflow, a wider one when this one held few pairs
+        if (kmax > 1u) st->win_shift = narrowed ? min(wshift + narrowed, 20u) : (n_win < 4u * kmax && wshift > 2u) ? wshift - 1u : wshift;
     }
     flag = __builtin_amdgcn_readfirstlane(flag);
     if (flag) return;
     YB_SEL_STAMP(3);
-    // ---- the walk (see the batch rule above select_body): positions 0, 1, ... of the window
+    // ---- the walk (the batch rule above select_body): the window's entries in selection order
     const uint32_t it0 = __builtin_amdgcn_readfirstlane(d_iter), num_merges = __builtin_amdgcn_readfirstlane(d_num_merges);
     const unsigned long long T_all = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(candT >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)candT);
     const unsigned long long minf = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(d_min_freq >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d_min_freq);
-    uint32_t nacc = 0;
-    for (uint32_t pos = 0; pos < n_win && nacc < kmax && it0 + nacc < num_merges; ++pos) {
-        const uint32_t ci = at_pos(pos);
-        if (ci >= (uint32_t)WIN) break;
-        const unsigned long long c_cnt = s_win[ci].cnt;
-        const uint32_t c_key = s_win[ci].key, c_rk = s_win[ci].rk, c_lx = s_win[ci].lx, c_ly = s_win[ci].ly;
-        const unsigned long long c_px = s_win[ci].px, c_py = s_win[ci].py;
-        const uint32_t p = c_key >> 16, q = c_key & 0xffffu;
+    uint32_t nacc = 0, why = 0;
+    (void)why;
+    while (true) {
+        const uint32_t p = cj.key >> 16, q = cj.key & 0xffffu;
         if (nacc) {
-            bool stop = c_cnt < T_all || c_cnt < minf || c_cnt == 0ull;
-            for (uint32_t i = 0; i < nacc; ++i) stop |= q == s_acc[i].a || p == s_acc[i].b; // rule (1)
-            // rule (2): the pairs that tie with the candidate and come after it
+            // rule (1): the candidate's own bit sets say whether q is some a_i or p some b_i
+            if (cj.cnt == 0ull || cj.cnt < T_all || cj.cnt < minf || cj.ralb) {
+                why = cj.ralb ? 1u : cj.cnt < T_all ? 3u : 5u;
+                break;
+            }
+            // rule (2): the pairs that tie with the candidate and come after it (not walked yet), with a token an accepted merge consumes
             bool blocks = false;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (mpos[h] == 0xffffffffu || mpos[h] <= pos || mc[h] != c_cnt) continue;
-                const uint32_t l = mkey[h] >> 16, r = mkey[h] & 0xffffu;
-                bool left_new_blocks = false, right_new = false, right_new_ge = false;
-                for (uint32_t i = 0; i < nacc; ++i) {
-                    const AccEnt A = s_acc[i];
-                    if (A.b == l) left_new_blocks |= cmp_pre8(A.pc, A.lc, c_px, c_lx) != -1; // (c_i, .) against (p, .)
-                    if (A.a == r) {
-                        right_new = true;
-                        right_new_ge |= cmp_pre8(A.pc, A.lc, c_py, c_ly) != -1; // (., c_i) against (., q)
-                    }
+                if (!mlive[h] || mc[h] != cj.cnt || (mra[h] | mlb[h]) == 0u) continue; // (rare from here on)
+                const uint32_t cwin = cj.win;
+                const unsigned long long c_px = s_win[cwin].px, c_py = s_win[cwin].py;
+                const uint32_t c_lx = s_win[cwin].lx, c_ly = s_win[cwin].ly;
+                bool left_new_blocks = false, right_new_ge = false;
+                for (uint32_t m = mlb[h]; m; m &= m - 1u) { // (c_i, .) against (p, .)
+                    const AccEnt A = s_acc[__ffs((int)m) - 1];
+                    left_new_blocks |= cmp_pre8(A.pc, A.lc, c_px, c_lx) != -1;
                 }
-                const uint32_t rl = mrk[h] >> 16, rp = c_rk >> 16; // lexranks of l and p
-                blocks |= left_new_blocks || (right_new && (rl > rp || (rl == rp && right_new_ge)));
+                for (uint32_t m = mra[h]; m; m &= m - 1u) { // (., c_i) against (., q)
+                    const AccEnt A = s_acc[__ffs((int)m) - 1];
+                    right_new_ge |= cmp_pre8(A.pc, A.lc, c_py, c_ly) != -1;
+                }
+                const uint32_t rl = mrk[h] >> 16, rp = cj.rk >> 16; // lexranks of l and p
+                blocks |= left_new_blocks || (mra[h] != 0u && (rl > rp || (rl == rp && right_new_ge)));
             }
-            if (stop || __any(blocks)) break;
+            if (__any(blocks)) {
+                why = 2u;
+                break;
+            }
         }
-        if (lane == 0) s_acc[nacc] = AccEnt{p, q, c_lx + c_ly, ci, pre8_concat(c_px, c_lx, c_py)};
+        // accept
+        if (lane == 0) {
+            const uint32_t cwin = cj.win;
+            s_acc[nacc] = AccEnt{p, q, s_win[cwin].lx + s_win[cwin].ly, cwin, pre8_concat(s_win[cwin].px, s_win[cwin].lx, s_win[cwin].py)};
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            mra[h] |= (uint32_t)((mkey[h] & 0xffffu) == p) << nacc;
+            mlb[h] |= (uint32_t)((mkey[h] >> 16) == q) << nacc;
+        }
         wave_sync();
         ++nacc;
-        if (p == q) break; // rule (3): a run merge closes the batch
+        if (p == q) { // rule (3): a run merge closes the batch
+            why = 6u;
+            break;
+        }
+        if (nacc >= kmax || it0 + nacc >= num_merges) {
+            why = 4u;
+            break;
+        }
+        cj = next_cand();
+        if (cj.cnt == 0ull) { // the window is walked through
+            why = 5u;
+            break;
+        }
     }
+    YB_STOP(it0, why, nacc, n_win);
     // ---- round trip 4: the merged tokens: one probe of the byte-string set each, side by side (lane k: merge k)
     unsigned long long Hk = 0ull, ve = VSET_EMPTY;
     uint32_t Lk = 0, vslot = 0, wk = 0;
