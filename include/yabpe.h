@@ -166,6 +166,13 @@ int yabpe_stream_checksum(yabpe_ctx *ctx, uint64_t *out_sum, uint64_t *out_words
 int yabpe_synth_generate(yabpe_ctx *ctx, uint64_t target_bytes, uint32_t n_types, uint64_t seed,
                          const uint8_t *alphabet, uint32_t alphabet_len, int space_prefix,
                          uint8_t **out_dev_bytes, uint64_t **out_dev_off, uint64_t *out_n_words, uint64_t *out_n_bytes);
+/* The same Zipf draw (w_j = floor(2^40 / (j+1)), u = rnd(seed,3,i) % sum w) over a lexicon the caller supplies (host arrays:
+   bytes + n_types+1 offsets, every entry 1..65,535 bytes): the drawn entries are concatenated until target_bytes is reached.
+   For synthetic TEXT (yet_another_bpe/synth.py text_lexicon: multi-byte UTF-8 words, digits, punctuation, whitespace runs,
+   long letter runs) whose pre-tokens yabpe_pretokenize then finds; out_dev_off are the piece boundaries (not pre-tokens). */
+int yabpe_synth_generate_lex(yabpe_ctx *ctx, uint64_t target_bytes, uint32_t n_types, uint64_t seed,
+                             const uint8_t *lex_bytes, const uint64_t *lex_off,
+                             uint8_t **out_dev_bytes, uint64_t **out_dev_off, uint64_t *out_n_pieces, uint64_t *out_n_bytes);
 int yabpe_synth_free(yabpe_ctx *ctx);
 /* Copy `n` bytes device->host / host->device (for fixtures and the CPU-baseline sample). */
 int yabpe_memcpy_d2h(yabpe_ctx *ctx, void *dst_host, const void *src_dev, uint64_t n);

@@ -47,6 +47,7 @@ typedef struct {
     int64_t count;
     uint32_t *words; /* inverted index; may hold stale/duplicate ids (reference keeps a superset too) */
     uint32_t n_words, cap_words;
+    uint64_t touched; /* iteration + 1 in which the count last changed (see the argmax) */
 } pair_t;
 
 typedef struct oracle_result {
@@ -157,6 +158,7 @@ static void ptab_init(ptab_t *t, uint64_t cap) {
         t->slots[i].count = 0;
         t->slots[i].words = NULL;
         t->slots[i].n_words = t->slots[i].cap_words = 0;
+        t->slots[i].touched = 0;
     }
 }
 
@@ -196,6 +198,58 @@ static void pair_index_add(pair_t *p, uint32_t w) {
     p->words[p->n_words++] = w;
 }
 
+/* ---------- argmax (trainer.py:246) ----------
+ * max(pair_counts.items(), key=lambda x: (x[1], x[0])) is a function of the table's contents only: the pair with the
+ * greatest (count, bytes(left), bytes(right)).  Scanning the whole table for it every iteration (what the reference's max()
+ * does) makes a job with millions of distinct pairs take hours on one core, so the SAME maximum is kept available in a
+ * binary heap of (count, pair) snapshots ordered by that very key: every pair is pushed when its count changes (once per
+ * iteration, with the count it ends the iteration on), a snapshot whose count is no longer the pair's is stale and
+ * dropped when it surfaces.  Every pair with a positive count has its current snapshot in the heap, so the first snapshot
+ * that is not stale is the table's maximum.  tests/test_oracle_golden.py pins the result on the reference's vectors,
+ * among them the 8,199-merge run whose iterations mostly have ties for the top count. */
+typedef struct {
+    int64_t count;
+    uint64_t key;
+} snap_t;
+typedef struct {
+    snap_t *a;
+    uint64_t n, cap;
+} heap_t;
+static const tok_t *g_toks; /* (the heap orders by token bytes) */
+static int snap_gt(const snap_t *x, const snap_t *y) {
+    if (x->count != y->count) return x->count > y->count;
+    int c = tok_cmp(&g_toks[x->key >> 32], &g_toks[y->key >> 32]);
+    if (c == 0) c = tok_cmp(&g_toks[(uint32_t)x->key], &g_toks[(uint32_t)y->key]);
+    return c > 0;
+}
+static void heap_push(heap_t *h, snap_t v) {
+    if (h->n == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : 1024;
+        h->a = (snap_t *)realloc(h->a, sizeof(snap_t) * h->cap);
+    }
+    uint64_t i = h->n++;
+    while (i) {
+        uint64_t p = (i - 1) >> 1;
+        if (!snap_gt(&v, &h->a[p])) break;
+        h->a[i] = h->a[p];
+        i = p;
+    }
+    h->a[i] = v;
+}
+static void heap_pop(heap_t *h) {
+    snap_t v = h->a[--h->n];
+    uint64_t i = 0;
+    for (;;) {
+        uint64_t l = 2 * i + 1, r = l + 1, m;
+        if (l >= h->n) break;
+        m = (r < h->n && snap_gt(&h->a[r], &h->a[l])) ? r : l;
+        if (!snap_gt(&h->a[m], &v)) break;
+        h->a[i] = h->a[m];
+        i = m;
+    }
+    if (h->n) h->a[i] = v;
+}
+
 /* ---------- word dedup table (trainer.py:221-225) ---------- */
 
 typedef struct {
@@ -204,9 +258,22 @@ typedef struct {
     uint64_t cap;
 } wtab_t;
 
+/* freq: occurrences of each input word (NULL: 1 each).  Equal words are pooled and their counts added, exactly what
+   word_freq[word] += 1 (trainer.py:221-225) gives when the occurrences come one by one: a caller that has already pooled
+   its pre-tokens (an 8 GiB text does not fit as a list of occurrences) passes the pooled words with their counts. */
+oracle_result *bpe_oracle_train_weighted(const uint8_t *bytes, const uint64_t *off, const uint64_t *freq, uint64_t n_words,
+                                         const uint8_t *sp_bytes, const uint32_t *sp_off, uint32_t n_specials,
+                                         uint64_t vocab_size, uint64_t min_frequency, double max_seconds);
+
 oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint64_t n_words,
                                 const uint8_t *sp_bytes, const uint32_t *sp_off, uint32_t n_specials,
                                 uint64_t vocab_size, uint64_t min_frequency, double max_seconds) {
+    return bpe_oracle_train_weighted(bytes, off, NULL, n_words, sp_bytes, sp_off, n_specials, vocab_size, min_frequency, max_seconds);
+}
+
+oracle_result *bpe_oracle_train_weighted(const uint8_t *bytes, const uint64_t *off, const uint64_t *freq, uint64_t n_words,
+                                         const uint8_t *sp_bytes, const uint32_t *sp_off, uint32_t n_specials,
+                                         uint64_t vocab_size, uint64_t min_frequency, double max_seconds) {
     /* max_seconds > 0 bounds the merge loop's wall time (bench.py's cpu_baseline leg); 0 = run to the end */
     struct timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -255,7 +322,7 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
                 wt.hash[s] = h;
                 wt.wid[s] = (uint32_t)nw;
                 words[nw].len = (uint32_t)n;
-                words[nw].freq = 1;
+                words[nw].freq = freq ? freq[i] : 1;
                 words[nw].stamp = UINT32_MAX;
                 words[nw].tok = NULL;
                 wstart[nw] = off[i];
@@ -265,7 +332,7 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
             if (wt.hash[s] == h) {
                 word_t *w = &words[wt.wid[s]];
                 if (w->len == n && memcmp(bytes + wstart[wt.wid[s]], p, n) == 0) {
-                    w->freq++;
+                    w->freq += freq ? freq[i] : 1;
                     break;
                 }
             }
@@ -295,6 +362,14 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
         }
     }
     r->n_pairs_initial = pt.used;
+    heap_t hp = {NULL, 0, 0};
+    for (uint64_t s2 = 0; s2 < pt.cap; s2++)
+        if (pt.slots[s2].key != EMPTY_KEY && pt.slots[s2].count > 0) {
+            g_toks = r->toks;
+            heap_push(&hp, (snap_t){pt.slots[s2].count, pt.slots[s2].key});
+        }
+    uint64_t *touched = NULL; /* keys whose count changed in this iteration */
+    uint64_t n_touched = 0, cap_touched = 0;
 
     /* num_merges = max(0, vocab_size - len(vocab)) (trainer.py:238) */
     uint64_t num_merges = vocab_size > base_vocab ? vocab_size - base_vocab : 0;
@@ -317,18 +392,14 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
         }
         /* argmax (trainer.py:246): max over (count, (bytes(p0), bytes(p1))); only count > 0 exist */
         pair_t *best = NULL;
-        for (uint64_t s = 0; s < pt.cap; s++) {
-            pair_t *p = &pt.slots[s];
-            if (p->key == EMPTY_KEY || p->count <= 0) continue;
-            if (!best || p->count > best->count) {
+        g_toks = r->toks; /* (the token array may have been reallocated) */
+        while (hp.n) {
+            pair_t *p = ptab_get(&pt, hp.a[0].key);
+            if (p->count == hp.a[0].count && p->count > 0) {
                 best = p;
-                continue;
+                break;
             }
-            if (p->count == best->count) {
-                int c = tok_cmp(&r->toks[p->key >> 32], &r->toks[best->key >> 32]);
-                if (c == 0) c = tok_cmp(&r->toks[(uint32_t)p->key], &r->toks[(uint32_t)best->key]);
-                if (c > 0) best = p;
-            }
+            heap_pop(&hp); /* stale: the pair's count has moved on since this snapshot */
         }
         if (!best) break;                                      /* trainer.py:242-243 */
         if ((uint64_t)best->count < min_frequency) break;      /* trainer.py:247-248 */
@@ -370,6 +441,14 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
             for (uint32_t j = 0; j + 1 < w->len; j++) {
                 pair_t *p = ptab_get(&pt, ((uint64_t)w->tok[j] << 32) | w->tok[j + 1]);
                 p->count -= (int64_t)w->freq;
+                if (p->touched != it + 1) {
+                    p->touched = it + 1;
+                    if (n_touched == cap_touched) {
+                        cap_touched = cap_touched ? cap_touched * 2 : 1024;
+                        touched = (uint64_t *)realloc(touched, sizeof(uint64_t) * cap_touched);
+                    }
+                    touched[n_touched++] = p->key;
+                }
             }
             /* greedy left-to-right, non-overlapping rewrite (trainer.py:276-285) */
             if (w->len > scratch_cap) {
@@ -393,9 +472,24 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
                 pair_t *p = ptab_get(&pt, ((uint64_t)w->tok[k] << 32) | w->tok[k + 1]);
                 p->count += (int64_t)w->freq;
                 if (w->tok[k] == z || w->tok[k + 1] == z) pair_index_add(p, aff[a]);
+                if (p->touched != it + 1) {
+                    p->touched = it + 1;
+                    if (n_touched == cap_touched) {
+                        cap_touched = cap_touched ? cap_touched * 2 : 1024;
+                        touched = (uint64_t *)realloc(touched, sizeof(uint64_t) * cap_touched);
+                    }
+                    touched[n_touched++] = p->key;
+                }
             }
         }
         free(aff);
+        /* the pairs whose count changed get a fresh snapshot (the count they end this iteration on) */
+        g_toks = r->toks;
+        for (uint64_t q = 0; q < n_touched; q++) {
+            pair_t *p = ptab_get(&pt, touched[q]);
+            if (p->count > 0) heap_push(&hp, (snap_t){p->count, p->key});
+        }
+        n_touched = 0;
 
         if (r->n_merges == cap_m) {
             cap_m *= 2;
@@ -417,6 +511,8 @@ oracle_result *bpe_oracle_train(const uint8_t *bytes, const uint64_t *off, uint6
     free(pt.slots);
     free(mbuf);
     free(scratch);
+    free(hp.a);
+    free(touched);
     return r;
 }
 

@@ -35,6 +35,8 @@ def _lib() -> ctypes.CDLL:
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         lib.bpe_oracle_train.restype = vp
         lib.bpe_oracle_train.argtypes = [vp, vp, u64, vp, vp, u32, u64, u64, ctypes.c_double]
+        lib.bpe_oracle_train_weighted.restype = vp
+        lib.bpe_oracle_train_weighted.argtypes = [vp, vp, vp, u64, vp, vp, u32, u64, u64, ctypes.c_double]
         for name in ("bpe_oracle_n_merges", "bpe_oracle_n_tokens"):
             getattr(lib, name).restype = u32
             getattr(lib, name).argtypes = [vp]
@@ -63,20 +65,22 @@ def flatten(sequences) -> tuple[np.ndarray, np.ndarray]:
 
 
 def train_flat(flat: np.ndarray, off: np.ndarray, vocab_size: int, min_frequency: int, special_tokens,
-               return_ids: bool = False, max_seconds: float = 0.0):
+               return_ids: bool = False, max_seconds: float = 0.0, freq: np.ndarray | None = None):
     """Run the C oracle on flat words.  Returns (vocab: dict[bytes,int], merges: list[(bytes,bytes)])
-    exactly as BBPETrainer._merge_loop does (trainer.py:302); with return_ids also the id triples/counts."""
+    exactly as BBPETrainer._merge_loop does (trainer.py:302); with return_ids also the id triples/counts.
+    freq: occurrences per input word (words pooled by the caller, trainer.py:221-225)."""
     lib = _lib()
     flat = np.ascontiguousarray(flat, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
+    fq = None if freq is None else np.ascontiguousarray(freq, dtype=np.uint64)
     n_words = len(off) - 1
     sp = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in special_tokens]
     sp_bytes = np.frombuffer(b"".join(sp) or b"\0", dtype=np.uint8).copy()
     sp_off = np.zeros(len(sp) + 1, dtype=np.uint32)
     if sp:
         sp_off[1:] = np.cumsum([len(t) for t in sp])
-    h = lib.bpe_oracle_train(flat.ctypes.data if flat.size else None, off.ctypes.data, n_words,
-                             sp_bytes.ctypes.data, sp_off.ctypes.data, len(sp), int(vocab_size), int(min_frequency), float(max_seconds))
+    h = lib.bpe_oracle_train_weighted(flat.ctypes.data if flat.size else None, off.ctypes.data, None if fq is None else fq.ctypes.data, n_words,
+                                      sp_bytes.ctypes.data, sp_off.ctypes.data, len(sp), int(vocab_size), int(min_frequency), float(max_seconds))
     try:
         nm = lib.bpe_oracle_n_merges(h)
         nt = lib.bpe_oracle_n_tokens(h)

@@ -237,3 +237,31 @@ def gpu_fullsize_sharded(rank, world, dist):
     h = hashlib.sha256(res["left"].astype(np.uint32).tobytes() + res["right"].astype(np.uint32).tobytes() + res["merged"].astype(np.uint32).tobytes()).hexdigest()
     st = res["stats"]
     return h, int(res["n_merges"]), int(nw), int(nb), int(mism), int(st["n_words"]), int(st["exchanges"]), int(st["exchange_growths"])
+
+
+def gpu_device_text_sharded(rank, world, dist, meta_name):
+    """BASELINE configs[4] shape at the size of tests/golden/<meta_name>: every rank regenerates the synthetic text on the
+    (shared) GPU, pre-tokenises its chunks, pools them and joins the merge loop.  -> (id-triples digest, merges, pre-tokens here, words here)."""
+    import hashlib
+    import json
+
+    import numpy as np
+
+    from yet_another_bpe import _native, synth
+    from yet_another_bpe.distributed import train_device_text_sharded
+    from yet_another_bpe.trainer import BBPETrainerConfig
+
+    meta = json.loads((REPO / "tests" / "golden" / meta_name).read_text())
+    g = meta["generator"]
+    lb, lo = synth.text_lexicon(g["n_types"], g["seed"])
+
+    def make_text(ctx):
+        tb, _to, _np, tn = ctx.synth_generate_lex(g["target_bytes"], g["seed"], lb, lo)
+        assert tn == meta["text_bytes"]
+        return tb, tn
+
+    cfg = BBPETrainerConfig(vocab_size=257 + meta["n_merges"], min_frequency=meta["min_frequency"], special_tokens=meta["special_tokens"],
+                            chunk_size_bytes=meta["chunk_size_bytes"])
+    left, right, merged, count, st, n_pre = train_device_text_sharded(lambda: _native.Context(0), make_text, cfg, rank, world, transport="torch")
+    h = hashlib.sha256(left.astype(np.uint32).tobytes() + right.astype(np.uint32).tobytes() + merged.astype(np.uint32).tobytes()).hexdigest()
+    return h, len(left), int(n_pre), int(st["n_words"]), int(st["n_long_words"])

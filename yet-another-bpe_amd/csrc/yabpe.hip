@@ -1989,6 +1989,35 @@ int yabpe_synth_generate(yabpe_ctx *c, uint64_t target_bytes, uint32_t n_types, 
     return YABPE_OK;
 }
 
+int yabpe_synth_generate_lex(yabpe_ctx *c, uint64_t target_bytes, uint32_t n_types, uint64_t seed, const uint8_t *lex_bytes,
+                             const uint64_t *lex_off, uint8_t **out_dev_bytes, uint64_t **out_dev_off, uint64_t *out_n_pieces, uint64_t *out_n_bytes) {
+    if (!c || !lex_bytes || !lex_off || !n_types || !out_dev_bytes || !out_dev_off || !out_n_pieces || !out_n_bytes) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t j = 0; j < n_types; ++j)
+        if (lex_off[j + 1] <= lex_off[j] || lex_off[j + 1] - lex_off[j] > 0xFFFFu) return fail(c, YABPE_E_INVALID, "lexicon entry %u is empty or longer than 65,535 bytes", j);
+    // expected bytes per draw under the Zipf weights: how many draws the target needs (more if that falls short)
+    long double num = 0, den = 0;
+    for (uint32_t j = 0; j < n_types; ++j) {
+        const long double w = (long double)((1ull << 40) / (j + 1ull));
+        num += w * (long double)(lex_off[j + 1] - lex_off[j]);
+        den += w;
+    }
+    const double mean_len = (double)(num / den);
+    SynthOut so{};
+    int r = -2;
+    for (double slack = 1.02; r == -2 && slack < 3.0; slack *= 1.25)
+        r = synth_generate_lex(c->stream, target_bytes, n_types, seed, lex_bytes, (const unsigned long long *)lex_off,
+                               (unsigned long long)((double)target_bytes / mean_len * slack) + 65536, &so);
+    if (r != 0) return fail(c, r == -2 ? YABPE_E_INTERNAL : YABPE_E_HIP, "synthetic text generation failed (%d): %s", r, hipGetErrorString(hipGetLastError()));
+    c->synth_bufs.push_back(so.bytes);
+    c->synth_bufs.push_back(so.off);
+    *out_dev_bytes = so.bytes;
+    *out_dev_off = (uint64_t *)so.off;
+    *out_n_pieces = so.n_words;
+    *out_n_bytes = so.n_bytes;
+    return YABPE_OK;
+}
+
 int yabpe_synth_free(yabpe_ctx *c) {
     if (!c) return YABPE_E_INVALID;
     for (void *p : c->synth_bufs) dfree(p);

@@ -210,6 +210,85 @@ inline int synth_generate(hipStream_t s, unsigned long long target, uint32_t n_t
     return rc;
 }
 
+// ---------------------------------------------------------------- the same Zipf draw over a lexicon the caller supplies
+// (yet_another_bpe/synth.py: text_lexicon -- multi-byte UTF-8 words, digits, punctuation, whitespace runs, long runs): the
+// "words" drawn are pieces of TEXT, concatenated; the pre-tokeniser decides where the pre-tokens are.
+__global__ void k_synth_draw_lex(unsigned long long seed, unsigned long long n_cand, const unsigned long long *cum, uint32_t n_types,
+                                 const unsigned long long *lex_off, uint32_t *word_type, uint32_t *word_len) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    const unsigned long long u = synth_rnd(seed, 3, i) % cum[n_types - 1];
+    uint32_t lo = 0, hi = n_types;  // first j with cum[j] > u
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cum[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    word_type[i] = lo;
+    word_len[i] = (uint32_t)(lex_off[lo + 1] - lex_off[lo]);
+}
+__global__ void k_synth_fill_lex(const uint32_t *word_type, const unsigned long long *off, unsigned long long n_words,
+                                 const uint8_t *lex_bytes, const unsigned long long *lex_off, uint8_t *bytes) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const uint32_t ty = word_type[i];
+    uint8_t *dst = bytes + off[i];
+    const uint8_t *src = lex_bytes + lex_off[ty];
+    const uint32_t n = (uint32_t)(lex_off[ty + 1] - lex_off[ty]);
+    for (uint32_t k = 0; k < n; ++k) dst[k] = src[k];
+}
+
+// lex_bytes / lex_off: HOST arrays (n_types + 1 offsets).  n_cand: how many draws to make (>= the words the target needs).
+inline int synth_generate_lex(hipStream_t s, unsigned long long target, uint32_t n_types, unsigned long long seed,
+                              const uint8_t *lex_bytes, const unsigned long long *lex_off, unsigned long long n_cand, SynthOut *out) {
+    uint8_t *d_lb = nullptr, *d_bytes = nullptr;
+    unsigned long long *d_lo = nullptr, *d_cum = nullptr, *d_off = nullptr, *d_cut = nullptr;
+    uint32_t *d_wt = nullptr, *d_wl = nullptr;
+    std::vector<unsigned long long> cum(n_types);
+    unsigned long long acc = 0;
+    for (uint32_t j = 0; j < n_types; ++j) {
+        acc += (1ull << 40) / (j + 1ull);
+        cum[j] = acc;
+    }
+    const unsigned long long lex_total = lex_off[n_types];
+    int rc = -1;
+    do {
+        if (hipMalloc((void **)&d_lb, lex_total ? lex_total : 1) != hipSuccess) break;
+        if (hipMalloc((void **)&d_lo, ((size_t)n_types + 1) * 8) != hipSuccess) break;
+        if (hipMalloc((void **)&d_cum, (size_t)n_types * 8) != hipSuccess) break;
+        if (hipMalloc((void **)&d_wt, n_cand * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_wl, n_cand * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_off, (n_cand + 1) * 8) != hipSuccess) break;
+        if (hipMalloc((void **)&d_cut, 16) != hipSuccess) break;
+        if (hipMemcpy(d_lb, lex_bytes, lex_total, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_lo, lex_off, ((size_t)n_types + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_cum, cum.data(), (size_t)n_types * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+        hipLaunchKernelGGL(k_synth_draw_lex, dim3((uint32_t)((n_cand + 255) / 256)), dim3(256), 0, s, seed, n_cand, d_cum, n_types, d_lo, d_wt, d_wl);
+        if (hipGetLastError() != hipSuccess) break;
+        if (exclusive_scan<uint32_t>(s, d_wl, n_cand, d_off, n_cand + 1) != 0) break;
+        hipLaunchKernelGGL(k_synth_cut, dim3(1), dim3(1), 0, s, d_off, n_cand, target, d_cut);
+        unsigned long long cut[2];
+        if (hipMemcpyAsync(cut, d_cut, 16, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        if (cut[0] == 0) { rc = -2; break; }  // (not enough draws for the target)
+        if (hipMalloc((void **)&d_bytes, cut[1]) != hipSuccess) break;
+        hipLaunchKernelGGL(k_synth_fill_lex, dim3((uint32_t)((cut[0] + 255) / 256)), dim3(256), 0, s, d_wt, d_off, cut[0], d_lb, d_lo, d_bytes);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        out->bytes = d_bytes;
+        out->off = d_off;
+        out->n_words = cut[0];
+        out->n_bytes = cut[1];
+        d_bytes = nullptr;
+        d_off = nullptr;
+        rc = 0;
+    } while (0);
+    (void)hipFree(d_lb); (void)hipFree(d_lo); (void)hipFree(d_cum);
+    (void)hipFree(d_wt); (void)hipFree(d_wl); (void)hipFree(d_cut);
+    if (d_bytes) (void)hipFree(d_bytes);
+    if (d_off) (void)hipFree(d_off);
+    return rc;
+}
+
 // ================================================================ device-side pooling of equal words (trainer.py:221-225)
 __global__ void k_word_hash(const uint8_t *bytes, const unsigned long long *off, unsigned long long n, unsigned long long *hash) {
     const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;

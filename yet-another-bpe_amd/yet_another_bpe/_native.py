@@ -57,7 +57,7 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
 SYMBOLS = [
     "yabpe_abi_version", "yabpe_device_count", "yabpe_create", "yabpe_destroy", "yabpe_last_error", "yabpe_set_option",
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
-    "yabpe_iter_log", "yabpe_event_log", "yabpe_latency_probe", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_free",
+    "yabpe_iter_log", "yabpe_event_log", "yabpe_latency_probe", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_generate_lex", "yabpe_synth_free",
     "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_pretokenize", "yabpe_pretokenize_free",
     "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
 ]
@@ -91,6 +91,8 @@ def lib() -> ctypes.CDLL:
         L.yabpe_stream_checksum.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_generate.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32, c_int,
                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]
+        L.yabpe_synth_generate_lex.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_void_p,
+                                               POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]
         L.yabpe_synth_free.argtypes = [c_void_p]
         L.yabpe_pretokenize.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32,
                                         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64), POINTER(ctypes.c_int64)]
@@ -244,6 +246,15 @@ class Context:
         pb, po, nw, nb = c_void_p(), c_void_p(), c_uint64(0), c_uint64(0)
         self._chk(lib().yabpe_synth_generate(self._h, target_bytes, n_types, seed, al.ctypes.data, len(al),
                                              1 if space_prefix else 0, byref(pb), byref(po), byref(nw), byref(nb)))
+        return pb.value, po.value, nw.value, nb.value
+
+    def synth_generate_lex(self, target_bytes: int, seed: int, lex_bytes: np.ndarray, lex_off: np.ndarray):
+        """Synthetic text from a lexicon (synth.text_lexicon): -> (dev_bytes_ptr, dev_piece_off_ptr, n_pieces, n_bytes)."""
+        lb = np.ascontiguousarray(lex_bytes, dtype=np.uint8)
+        lo = np.ascontiguousarray(lex_off, dtype=np.uint64)
+        pb, po, nw, nb = c_void_p(), c_void_p(), c_uint64(0), c_uint64(0)
+        self._chk(lib().yabpe_synth_generate_lex(self._h, c_uint64(target_bytes), c_uint32(len(lo) - 1), c_uint64(seed), c_void_p(lb.ctypes.data),
+                                                 c_void_p(lo.ctypes.data), byref(pb), byref(po), byref(nw), byref(nb)))
         return pb.value, po.value, nw.value, nb.value
 
     def synth_free(self) -> None:

@@ -193,6 +193,40 @@ def train_text_sharded(ctx_factory, files, config, rank: int, world: int, transp
     return BBPEModel(vocab=vocab, merges=merges, special_tokens=specials)
 
 
+def train_device_text_sharded(ctx_factory, make_text, config, rank: int, world: int, transport: str = "rccl", options: dict | None = None):
+    """train_text_sharded for text that is produced ON the device (synthetic corpora at sizes a test cannot keep on disk):
+    `make_text(ctx) -> (dev_ptr, n_bytes)` runs on every rank; the chunk cuts are the reference's (config.chunk_size_bytes),
+    this rank pre-tokenises ITS chunks, pools the pre-tokens and joins the collective merge loop.
+    Returns (left, right, merged, count, stats, n_pretokens_here)."""
+    from .trainer import BBPETrainer, chunk_ranges
+
+    tr = BBPETrainer(config)
+    base = tr._base_tokens()
+    specials = list(config.special_tokens)
+    num_merges = max(0, config.vocab_size - len(base))
+    with ctx_factory() as ctx:
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_vocab(base)
+        attach(ctx, rank, world, transport)
+        ptr, n_bytes = make_text(ctx)
+        ranges = chunk_ranges(n_bytes, config.chunk_size_bytes, lambda off, n: ctx.d2h(ptr + off, n).tobytes())
+        c0, c1 = plan_chunk_shards([b - a for a, b in ranges], world)[rank]
+        mine = ranges[c0:c1]
+        n_words = 0
+        if mine:
+            a0 = mine[0][0]
+            assert all(mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1)), "chunks of valid UTF-8 follow one another"
+            dev_text, dev_off, n_words = ctx.pretokenize(ptr + a0, n_bytes=mine[-1][1] - a0, chunk_starts=[a - a0 for a, _ in mine],
+                                                         special_tokens=specials)
+        if n_words:
+            ctx.load_words_ptr(dev_text, dev_off, n_words, dedup=True)
+        else:
+            ctx.load_words(np.zeros(0, np.uint8), np.zeros(1, np.uint64), None, dedup=True)  # no words here: same layout as the peers
+        left, right, merged, count = ctx.train(num_merges, int(config.min_frequency))
+        return left, right, merged, count, ctx.stats(), n_words
+
+
 class ShardedRunner:
     """bench.py helper: the corpus is already on every rank's GPU; each rank trains on its word range."""
 

@@ -70,6 +70,29 @@ def _utf8_cut(window: bytes, pos: int) -> int:
     return pos
 
 
+def chunk_ranges(size: int, step: int, read) -> list[tuple[int, int]]:
+    """The reference's chunk cuts (get_chunks, trainer.py:172-198) for `size` bytes that `read(offset, n) -> bytes` gives
+    access to (a file, or text that lives on the device): a cut every `step` bytes, moved back to a UTF-8 boundary."""
+    if size == 0:
+        return []
+    if size <= step:
+        return [(0, size)]
+    ranges: list[tuple[int, int]] = []
+    start = 0
+    while start < size:
+        stop = min(start + step, size)
+        if stop < size:  # back off to a UTF-8 boundary using a 5-byte window (trainer.py:183-190)
+            w0 = max(0, stop - 4)
+            window = read(w0, stop + 1 - w0)
+            stop = w0 + _utf8_cut(window, stop - w0)
+        if stop > start:
+            ranges.append((start, stop))
+            start = stop
+        else:
+            start += 1  # no progress possible: the reference skips one byte (trainer.py:196-197)
+    return ranges
+
+
 class BBPETrainer:
     """Byte-level BPE trainer with the reference's API; the merge loop runs on the GPU."""
 
@@ -211,27 +234,12 @@ class BBPETrainer:
     # ------------------------------------------------------------------ pre-tokenisation (trainer.py:136-214)
     def _chunk_ranges(self, path: Path) -> list[tuple[int, int]]:
         size = path.stat().st_size
-        step = self.config.chunk_size_bytes
-        if size == 0:
-            return []
-        if size <= step:
-            return [(0, size)]
-        ranges: list[tuple[int, int]] = []
         with open(path, "rb") as f:
-            start = 0
-            while start < size:
-                stop = min(start + step, size)
-                if stop < size:  # back off to a UTF-8 boundary using a 5-byte window (trainer.py:183-190)
-                    w0 = max(0, stop - 4)
-                    f.seek(w0)
-                    window = f.read(stop + 1 - w0)
-                    stop = w0 + _utf8_cut(window, stop - w0)
-                if stop > start:
-                    ranges.append((start, stop))
-                    start = stop
-                else:
-                    start += 1  # no progress possible: the reference skips one byte (trainer.py:196-197)
-        return ranges
+            def read(off: int, n: int) -> bytes:
+                f.seek(off)
+                return f.read(n)
+
+            return chunk_ranges(size, self.config.chunk_size_bytes, read)
 
     def _split_pattern(self) -> "regex.Pattern[str]":
         pat = _GPT2_SPLIT
