@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BPE training hot path on MI355X: merges/s (+ corpus bytes/s) to 32k merges on the 1 GiB
 synthetic byte corpus of SURVEY.md 8(d) config 3, with the bound of each phase of the timed job -- the HBM roofline of
-the streaming phase (fused k_apply, whole iterations) and the dependent-trip floor of the sparse phase (k_scan_skip) -- and
-the reference's algorithm in pure Python on the host as the CPU baseline.
+the streaming phase (fused k_apply, whole iterations) and the dependent-trip floor of the sparse phase (k_scan_skip: one
+launch applies a BATCH of merges) -- and the reference's algorithm in pure Python on the host as the CPU baseline.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -86,10 +86,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--target-mib", type=int, default=1024)
     ap.add_argument("--merges", type=int, default=32000)
-    ap.add_argument("--event-sample", type=int, default=64, help="time every Nth sparse-phase launch with HIP events (0 = off)")
+    ap.add_argument("--event-sample", type=int, default=0, help="time every Nth sparse-phase launch with HIP events too (0 = off: the phase is timed as a whole)")
     ap.add_argument("--event-sample-dense", type=int, default=2, help="... every Nth launch of the streaming phase (fused k_apply)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
-    ap.add_argument("--roofline-merges", type=int, default=1200, help="merges of the auxiliary scan-only pass (0 = skip it)")
+    ap.add_argument("--long-words", type=int, default=0, help="auxiliary line: the job on 256 MiB of the corpus with N words of 64..300 bytes added (the long-word path), next to the same job without them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup-line", action="store_true")
     ap.add_argument("--no-pretok-line", action="store_true")
@@ -137,12 +137,12 @@ def main() -> None:
     else:
         runner = None
 
-    def one_job(dedup: bool, event_sample: int):
+    def one_job(dedup: bool, event_sample: int, timed: bool = False):
         if runner is not None:
             return runner.run(args.merges, 1, dedup=dedup, event_sample=event_sample)
         with _native.Context(local_rank) as ctx:
             ctx.set_option("event_sample", event_sample)
-            ctx.set_option("event_sample_dense", args.event_sample_dense if event_sample else 0)
+            ctx.set_option("event_sample_dense", args.event_sample_dense if timed else 0)
             ctx.set_vocab(base)
             ctx.load_words_ptr(pb, po, n_words, dedup=dedup)
             left, right, merged, count = ctx.train(args.merges, 1)
@@ -169,7 +169,7 @@ def main() -> None:
     t0 = time.perf_counter()
     res = None
     for _ in range(args.steps):
-        res = one_job(False, args.event_sample)
+        res = one_job(False, args.event_sample, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -196,15 +196,17 @@ def main() -> None:
     if world > 1:
         out["exchange"] = {"all_gathers": st["exchanges"], "bytes_received_per_merge": st["exchange_bytes"], "record_capacity_per_rank": st["exchange_cap_records"],
                            "buffer_growths": st["exchange_growths"], "max_records_of_a_rank_at_a_batch_end": st["exchange_max_records"],
-                           "note": "per merge: apply launch (deltas leave as records) -> one all-gather of [header | records] -> one launch that adds "
-                                   "every rank's records to the replica and selects the next merge"}
+                           "merges_per_exchange": round(n_merges / max(1, st["exchanges"]), 2),
+                           "note": "per batch of merges: apply launch (deltas leave as records) -> one all-gather of [header | records] -> one launch that adds "
+                                   "every rank's records to the replica and selects the next batch"}
     # ---- what bounds the timed job.  It has two phases:
     #   streaming (the first few hundred merges, most tiles change): ONE fused launch per merge, k_apply -- a coalesced read of
     #   the whole live token stream + rewrite + pair-table update + the selection of the next merge.  HBM-bound by design:
     #   `roofline` = sum of A_i = 2 (T_i + W) over its event-timed launches / their summed time (whole iterations).
-    #   sparse (the rest: a tile-level skip index finds the ~1 % of the tiles that hold the pair): ONE fused launch per merge,
-    #   k_scan_skip -- a chain of dependent memory trips, not a streaming kernel.  `latency` = its measured time per merge
-    #   against a floor built from pieces measured on this device in this run (yabpe_latency_probe).
+    #   sparse (the rest: a tile-level skip index finds the ~1 % of the tiles that hold a pair): ONE fused launch per BATCH of
+    #   merges (the selection fixes up to 16 consecutive merges it can prove independent), k_scan_skip -- a chain of dependent
+    #   memory trips per launch, not a streaming kernel.  `latency` = its measured time per launch against a floor built from
+    #   pieces measured on this device in this run (yabpe_latency_probe), and the resulting time per merge.
     phase_ms = {"streaming": round(st["train_ms"] - st["sparse_ms"], 2), "sparse": round(st["sparse_ms"], 2)}
     out["device_ms"]["phases"] = phase_ms
     if st["dense_launches_sampled"]:
@@ -242,22 +244,30 @@ def main() -> None:
         lat = gen.latency_probe()
         n_load, n_coh, n_atomic = 4, 4, 3
         floor = lat["launch_gap_us"] + n_load * lat["load_trip_us"] + n_coh * lat["coherent_trip_us"] + n_atomic * lat["atomic_trip_us"]
-        achieved_us = 1000.0 * st["sparse_ms"] / st["sparse_merges"]
+        launches = max(1, st["sparse_launches"])
+        per_launch = 1000.0 * st["sparse_ms"] / launches
+        per_merge = 1000.0 * st["sparse_ms"] / st["sparse_merges"]
+        tail_launch = 1000.0 * st["tail_ms"] / max(1, st["tail_launches"])
         out["latency"] = {
-            "kernel": "k_scan_skip (fused per-merge launch of the sparse phase)", "bound": "dependent memory trips",
-            "floor_us_per_merge": round(floor, 2), "achieved_us_per_merge": round(achieved_us, 2), "frac": round(floor / achieved_us, 4),
-            "merges": st["sparse_merges"], "share_of_merge_loop_time": round(phase_ms["sparse"] / max(st["train_ms"], 1e-9), 4),
+            "kernel": "k_scan_skip (fused launch of the sparse phase: applies a batch of merges, selects the next batch)", "bound": "dependent memory trips per launch",
+            "floor_us_per_launch": round(floor, 2), "achieved_us_per_launch": round(per_launch, 2), "frac": round(floor / per_launch, 4),
+            "merges": st["sparse_merges"], "launches": st["sparse_launches"], "mean_batch": round(st["sparse_merges"] / launches, 2),
+            "achieved_us_per_merge": round(per_merge, 2),
+            "share_of_merge_loop_time": round(phase_ms["sparse"] / max(st["train_ms"], 1e-9), 4),
             "second_half_us_per_merge": round(1000.0 * st["tail_ms"] / max(1, st["tail_merges"]), 2),
-            "second_half_frac": round(floor / (1000.0 * st["tail_ms"] / max(1, st["tail_merges"])), 4) if st["tail_merges"] else None,
+            "second_half_us_per_launch": round(tail_launch, 2) if st["tail_launches"] else None,
+            "second_half_mean_batch": round(st["tail_merges"] / max(1, st["tail_launches"]), 2) if st["tail_launches"] else None,
+            "second_half_frac": round(floor / tail_launch, 4) if st["tail_launches"] else None,
             "pieces_us": {k: round(v, 3) for k, v in lat.items()},
-            "model": f"floor = 1 launch boundary + {n_load} cache-missing loads (merge record, signature word, tile, byte-string set probe) + "
-                     f"{n_coh} device-scope loads (table key, candidate list, counts, records of the tied pairs) + {n_atomic} returning atomics "
-                     "(count add, two ticket levels): the dependent chain of one merge when every step takes one idle-device trip and "
-                     "compute, imbalance and queueing take nothing; achieved = the whole sparse phase (its first merges still have 10^5 "
-                     "sites each) including the host's housekeeping between batches (candidate-list and signature rebuilds, table growth, "
+            "model": f"floor of ONE launch = 1 launch boundary + {n_load} cache-missing loads (batch record, signature word, tile, byte-string set probe) + "
+                     f"{n_coh} device-scope loads (table key, candidate list, counts, records of the window's pairs) + {n_atomic} returning atomics "
+                     "(count add, two ticket levels): the dependent chain of a launch when every step takes one idle-device trip and compute, "
+                     "bandwidth, imbalance and queueing take nothing -- whatever the number of merges it applies.  achieved = the whole sparse "
+                     "phase (its first merges still have 10^5 sites each: those launches are bound by the tiles they read, not by trips) "
+                     "including the host's housekeeping between rounds of launches (candidate-list and signature rebuilds, table growth, "
                      "retile); second_half_* = the same for the last half of the merges, where a merge has a few thousand sites",
         }
-        if st["apply_launches_sampled"] and st["scan_skip_launches"]:
+        if st["apply_launches_sampled"] and st["scan_launches_sampled"]:
             n_l = st["scan_launches_sampled"]
             tiles_read = st["scan_skip_tiles_read"] / max(1, st["scan_skip_launches"])
             out["latency"]["event_timed"] = {"launches": n_l, "avg_launch_us": round(1e3 * st["scan_ms_sampled"] / max(1, n_l), 2),
@@ -304,6 +314,26 @@ def main() -> None:
                                   "offsets_equal_generator_words": same_offsets, "cpu_baseline": cpu_pt,
                                   "note": "yabpe_pretokenize (UTF-8 validation + GPT-2 split + special tokens -> word offsets in HBM), "
                                           "wall time incl. scratch allocation, best of 3; not part of `value`"}
+    if rank == 0 and args.long_words > 0 and world == 1:
+        # the long-word path (words of more than 63 tokens live outside the tile stream): what it costs per merge, measured
+        import numpy as np
+
+        flat, off, k = _leading_words(gen, pb, po, n_words, 256 << 20)
+        rng = np.random.default_rng(7)
+        ll = rng.integers(64, 301, size=args.long_words).astype(np.uint64)
+        lflat = rng.choice(np.frombuffer(b"etaoinshrdlu", dtype=np.uint8), size=int(ll.sum())).astype(np.uint8)
+        off2 = np.concatenate([off, off[-1] + np.cumsum(ll)]).astype(np.uint64)
+        flat2 = np.concatenate([flat, lflat])
+        res_lw = {}
+        for name, (f_, o_) in {"without": (flat, off), "with": (flat2, off2)}.items():
+            with _native.Context(local_rank) as ctx:
+                ctx.set_vocab(base)
+                ctx.load_words(f_, o_)
+                l_, _r, _m, _c = ctx.train(min(args.merges, 8000), 1)
+                s_ = ctx.stats()
+                res_lw[name] = {"merges": len(l_), "merge_loop_ms": round(s_["train_ms"], 2), "us_per_merge": round(1000.0 * s_["train_ms"] / max(1, len(l_)), 2),
+                                "long_words": s_["n_long_words"]}
+        out["long_words"] = {"corpus": f"first {int(off[-1])} bytes of the corpus, + {args.long_words} words of 64..300 random letters", **res_lw}
     if rank == 0 and not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N=1 item)
         out["cpu_baseline"] = cpu_baseline(gen, pb, po, n_words, args.merges, args.cpu_sample_mib << 20, specials)
         out["cpu_baseline_c_port"] = cpu_baseline_c_port(gen, pb, po, n_words, args.merges, 32 << 20, specials)

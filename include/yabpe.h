@@ -134,6 +134,8 @@ typedef struct yabpe_stats_t {
     uint64_t exchanges, exchange_bytes, exchange_cap_records, exchange_growths, exchange_max_records;
     /* launches of the sparse phase: one launch applies a BATCH of merges (sparse_merges / sparse_launches = mean batch) */
     uint64_t sparse_launches;
+    /* ... and the launches of the second half of each yabpe_train call's merges (tail_merges / tail_launches = mean batch there) */
+    uint64_t tail_launches;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

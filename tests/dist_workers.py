@@ -164,9 +164,11 @@ def gpu_sharded(rank, world, dist, scenario):
     sp = ["<|endoftext|>"]
     base = helpers.base_tokens(sp)
     opts = {"verify": 1}
-    if scenario == "corpus_en_flat":
+    if scenario in ("corpus_en_flat", "corpus_en_flat_direct_store"):
         flat, off = helpers.flatten(helpers.corpus_en_words())
         freq, merges = None, 700
+        if scenario == "corpus_en_flat_direct_store":  # the streaming form throughout: its direct-indexed delta store flushes into the
+            opts.update({"split": 0, "hist": 1})      # send buffer four times back to back per launch (the race fixed in e85c033)
     elif scenario == "corpus_en_weighted":
         uw, fq = helpers.pooled(helpers.corpus_en_words())
         flat, off = helpers.flatten(uw)
@@ -239,7 +241,7 @@ def gpu_fullsize_sharded(rank, world, dist):
     return h, int(res["n_merges"]), int(nw), int(nb), int(mism), int(st["n_words"]), int(st["exchanges"]), int(st["exchange_growths"])
 
 
-def gpu_device_text_sharded(rank, world, dist, meta_name):
+def gpu_device_text_sharded(rank, world, dist, meta_name, n_merges=None):
     """BASELINE configs[4] shape at the size of tests/golden/<meta_name>: every rank regenerates the synthetic text on the
     (shared) GPU, pre-tokenises its chunks, pools them and joins the merge loop.  -> (id-triples digest, merges, pre-tokens here, words here)."""
     import hashlib
@@ -260,8 +262,16 @@ def gpu_device_text_sharded(rank, world, dist, meta_name):
         assert tn == meta["text_bytes"]
         return tb, tn
 
-    cfg = BBPETrainerConfig(vocab_size=257 + meta["n_merges"], min_frequency=meta["min_frequency"], special_tokens=meta["special_tokens"],
+    cfg = BBPETrainerConfig(vocab_size=257 + (n_merges or meta["n_merges"]), min_frequency=meta["min_frequency"], special_tokens=meta["special_tokens"],
                             chunk_size_bytes=meta["chunk_size_bytes"])
     left, right, merged, count, st, n_pre = train_device_text_sharded(lambda: _native.Context(0), make_text, cfg, rank, world, transport="torch")
     h = hashlib.sha256(left.astype(np.uint32).tobytes() + right.astype(np.uint32).tobytes() + merged.astype(np.uint32).tobytes()).hexdigest()
-    return h, len(left), int(n_pre), int(st["n_words"]), int(st["n_long_words"])
+    # the byte-level merges list as the golden files serialise it (for a prefix of the job only the prefix digests apply)
+    toks = [bytes([b]) for b in range(256)] + [t.encode() for t in meta["special_tokens"]]
+    lines = []
+    for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
+        lines.append(f"{toks[l].hex()} {toks[r].hex()}\n")
+        if m == len(toks):
+            toks.append(toks[l] + toks[r])
+    hm = hashlib.sha256("".join(lines).encode()).hexdigest()
+    return h, len(left), int(n_pre), int(st["n_words"]), int(st["n_long_words"]), hm

@@ -270,3 +270,27 @@ class TestTokenizerOnTrainedModel:
         tok = BBPETokenizer.from_file(tmp_path / "m")
         ids = tok.encode("Hello<|endoftext|>World")
         assert tok.get_vocab()["<|endoftext|>"] in ids and tok.decode(ids) == "Hello<|endoftext|>World"
+
+
+def test_benchmark_script_runs_and_reports_the_reference_fields(capsys):
+    """tools/benchmark_trainer.py mirrors the reference's tests/benchmark_trainer.py (:13-94: train() end to end
+    on corpus.en at vocab 500 and 1000, three runs each, plus a larger text; mean / min time, final vocab size, merges learned).
+    The script must run and report those fields; its last stdout line is the JSON record (gpurun_out keeps one per round)."""
+    import importlib.util
+    import json
+    from pathlib import Path
+
+    path = Path(__file__).resolve().parent.parent / "tools" / "benchmark_trainer.py"
+    spec = importlib.util.spec_from_file_location("benchmark_trainer", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    line = mod.main()
+    printed = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert printed == line and line["benchmark"] == "BBPETrainer.train" and len(line["cases"]) == 3
+    by_target = {(c["corpus"], c["vocab_size_target"]): c for c in line["cases"]}
+    small = by_target[("corpus.en", 500)]
+    assert small["runs"] == 3 and small["vocab_size"] == 500 and small["merges_count"] == 500 - 257
+    assert by_target[("corpus.en", 1000)]["merges_count"] == 1000 - 257
+    for c in line["cases"]:
+        assert 0 < c["min_time_s"] <= c["mean_time_s"] <= c["max_time_s"] and c["merges_count"] > 0
+    assert small["min_time_s"] < 1.5  # the reference's own speed bound for this case (tests/test_train_bpe_gpt2.py:24)

@@ -53,6 +53,16 @@ def test_four_ranks_one_gpu(scenario):
     assert all(o[1] > 0 for o in outs)
 
 
+def test_four_ranks_direct_store_flushes_into_the_send_buffer():
+    """Named regression case: four ranks, streaming form only, direct-indexed delta store -- hist_flush calls the
+    record sink of flush_entries once per role, back to back; the sink's LDS scratch (s_wtot / s_sbase) was rewritten under slower
+    waves until the helper ended on a barrier (commit e85c033: an intermittent wrong count with 4 ranks)."""
+    exp = _expect("corpus_en_flat")
+    outs = dist_workers.spawn(dist_workers.gpu_sharded, 4, "corpus_en_flat_direct_store", timeout=900)
+    for merges, n_words, rebuilds, retiles in outs:
+        assert [(bytes.fromhex(a), bytes.fromhex(b)) for a, b in merges] == exp
+
+
 def test_rccl_transport_single_rank_smoke():
     """The real RCCL calls (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the compute stream) with a
     1-rank communicator: the exchange path runs end to end through librccl and must not change the result."""

@@ -38,7 +38,7 @@ def synthetic_text(path: Path, target_bytes: int) -> None:
     path.write_bytes(flat.tobytes())
 
 
-def main() -> None:
+def main() -> dict:
     cases = [("Small corpus (corpus.en)", REPO / "tests/golden/corpus.en", 500, 3),
              ("Small corpus, larger vocab", REPO / "tests/golden/corpus.en", 1000, 3)]
     out = []
@@ -56,7 +56,9 @@ def main() -> None:
             print(f"\n{title}\n" + "-" * 40)
             print(f"  Vocab size target: {vs}\n  Final vocab size: {r['vocab_size']}\n  Merges learned: {r['merges_count']}")
             print(f"  Mean time: {r['mean_time_s']:.3f}s\n  Min time:  {r['min_time_s']:.3f}s")
-    print("\n" + json.dumps({"benchmark": "BBPETrainer.train", "cases": out}))
+    line = {"benchmark": "BBPETrainer.train", "cases": out}
+    print("\n" + json.dumps(line))
+    return line
 
 
 if __name__ == "__main__":

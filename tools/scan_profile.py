@@ -18,6 +18,7 @@ with _native.Context() as g:
     pb, po, nw, nb = g.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
     with _native.Context() as ctx:
         ctx.set_option("full_wpb", WPB)
+        if os.environ.get("BATCH_MAX"): ctx.set_option("batch_max", int(os.environ["BATCH_MAX"]))
         ctx.set_vocab(base); ctx.load_words_ptr(pb, po, nw, dedup=bool(int(os.environ.get("DEDUP", "0"))))  # DEDUP=1: the pooled layout
         done = 0
         for m in merges:
@@ -35,12 +36,13 @@ with _native.Context() as g:
             scan = scan[scan[:, 0] > recent]
             t0 = min(scan[:, 0].min(), rank[:, 0].min() if len(rank) else scan[:, 0].min())
             us = lambda x: x / 100.0
-            print(f"--- after {m} merges: n_tiles {st['n_tiles']} scan blocks {n_scan} rank blocks {len(rank)}")
+            kk = scan[:, 3] >> 32; ncand = scan[:, 3] & 0xffffffff
+            print(f"--- after {m} merges: n_tiles {st['n_tiles']} scan blocks {n_scan} rank blocks {len(rank)} | merges in the profiled launch {int(np.median(kk))}, candidate tiles per workgroup mean {ncand.mean():.1f} max {ncand.max()} (per wave {ncand.mean() / WPB:.2f})")
             print(f"span scan blocks: first start 0, last start {us(scan[:,0].max()-t0):.2f}, last end {us(scan[:,7].max()-t0):.2f} us")
             if len(rank):
                 print(f"rank blocks: start {us(rank[:,0].min()-t0):.2f}..{us(rank[:,0].max()-t0):.2f}, end max {us(rank[:,7].max()-t0):.2f}, dur mean {us((rank[:,7]-rank[:,0]).mean()):.2f} max {us((rank[:,7]-rank[:,0]).max()):.2f}")
-            names = ["start->merge arrived", "merge->LDS initialised", "LDS init->sig tested", "sig->candidates matched", "cand->rewrites done", "rewrites->loop left", "flush (epilogue)"]
-            idx = [(0, 5), (5, 6), (6, 1), (1, 2), (2, 3), (3, 4), (4, 7)]
+            names = ["merge->LDS initialised", "LDS init->sig tested", "sig->candidates matched", "cand->loop left", "flush (epilogue)"]
+            idx = [(5, 6), (6, 1), (1, 2), (2, 4), (4, 7)]
             for nm, (a, b) in zip(names, idx):
                 d = us(scan[:, b] - scan[:, a])
                 print(f"  {nm:28s} mean {d.mean():7.2f}  p50 {np.percentile(d,50):7.2f}  p99 {np.percentile(d,99):7.2f}  max {d.max():7.2f} us")

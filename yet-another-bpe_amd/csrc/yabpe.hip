@@ -1104,18 +1104,25 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
         HIPCHK(c, hipMemcpy(lw.data(), d_long_word, (size_t)c->n_long * 4, hipMemcpyDeviceToHost));
         std::sort(lw.begin(), lw.end());  // deterministic layout
         HIPCHK(c, hipMemcpy(d_long_word, lw.data(), (size_t)c->n_long * 4, hipMemcpyHostToDevice));
-        std::vector<unsigned long long> loff(c->n_long + 1, 0);
-        for (uint32_t i = 0; i < c->n_long; ++i) {
-            unsigned long long o[2];
-            HIPCHK(c, hipMemcpy(o, d_off + lw[i], 16, hipMemcpyDeviceToHost));
-            loff[i + 1] = loff[i] + (o[1] - o[0]);
-            if (o[1] - o[0] > 0xFFFFFFFFull) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "a single word longer than 2^32-1 bytes"); }
-        }
-        TRY(dmalloc(c, &c->long_tok, loff[c->n_long]));
+        // where each long word goes: prefix sum of their lengths, on the device
+        uint32_t *d_ll = nullptr;
+        TRY(dmalloc(c, &d_ll, c->n_long));
         TRY(dmalloc(c, &c->long_off, c->n_long + 1));
+        HIPCHK(c, hipMemsetAsync(&c->scratch64[2], 0, 8, c->stream));
+        hipLaunchKernelGGL(k_long_lengths, dim3(cdiv64(c->n_long, 256)), dim3(256), 0, c->stream, d_off, d_long_word, c->n_long, d_ll, (uint32_t *)&c->scratch64[2]);
+        HIPCHK(c, hipGetLastError());
+        if (exclusive_scan<uint32_t>(c->stream, d_ll, c->n_long, c->long_off, (unsigned long long)c->n_long + 1) != 0) {
+            cleanup_inputs();
+            return fail(c, YABPE_E_HIP, "long-word scan failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        unsigned long long long_total = 0, too_long = 0;
+        HIPCHK(c, hipMemcpy(&long_total, c->long_off + c->n_long, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&too_long, &c->scratch64[2], 8, hipMemcpyDeviceToHost));
+        dfree(d_ll);
+        if (too_long & 0xFFFFFFFFull) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "a single word longer than 2^32-1 bytes"); }
+        TRY(dmalloc(c, &c->long_tok, long_total));
         TRY(dmalloc(c, &c->long_len, c->n_long));
         if (c->weighted) TRY(dmalloc(c, &c->long_freq, c->n_long));
-        HIPCHK(c, hipMemcpy(c->long_off, loff.data(), (size_t)(c->n_long + 1) * 8, hipMemcpyHostToDevice));
         LoadLongParams L{d_bytes, d_off, d_freq, d_long_word, c->long_off, c->long_tok, c->long_len, c->long_freq, c->n_long};
         hipLaunchKernelGGL(k_load_long, dim3(c->n_long), dim3(BLOCK), 0, c->stream, L);
         HIPCHK(c, hipGetLastError());
@@ -1164,6 +1171,7 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.sparse_launches = 0;
     c->stats.tail_ms = 0;
     c->stats.tail_merges = 0;
+    c->stats.tail_launches = 0;
     c->stats.scan_ms_sampled = 0;
     c->stats.scan_launches_sampled = 0;
     c->stats.scan_algo_bytes_sampled = 0;
@@ -1243,10 +1251,13 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         ev->split = c->split_mode;
         HIPCHK(c, hipEventRecord(ev->e0, c->stream));
     }
-    if (fuse_kernel && c->n_long) {  // the long words first: the fused launch must be the last one to touch the table
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
-        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, L);
-    }
+    // the long words (more than 63 tokens: outside the tile stream) ride on the fused launch as extra workgroups, like the
+    // lexrank maintenance: one signature word per long word and merge, the few words that pass are rewritten
+    const LongParams LW{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
+    const bool long_rides = fuse_kernel && c->n_long && c->n_tiles && rank_rides;
+    const uint32_t long_blocks = long_rides ? cdiv64(c->n_long, BLOCK) : 0u;
+    if (fuse_kernel && c->n_long && !long_rides)  // (no tile launch to ride on: on their own, first -- the fused launch must be the last one to touch the table)
+        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, LW);
     // the fused selection folds the per-workgroup counters of THIS launch too: it must know the larger grid
     auto fuse_params = [&](uint32_t grid_now) {
         FuseParams F{};
@@ -1262,13 +1273,14 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         if (!c->split_mode) {
             // streaming form: one merge per launch, one coalesced pass over the live stream
             const FuseParams F = fuse_params(apply_grid);
+            const uint32_t rr_blocks = rank_rides ? rank_blocks : 0u;
             c->blk_used = std::max(c->blk_used, apply_grid);
             if (c->weighted)
-                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
             else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V)  // (every token id this launch can meet indexes the direct store)
-                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
+                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
             else
-                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + (rank_rides ? rank_blocks : 0u)), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F);
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
             // sparse form: skip index + rewrite of the tiles that pass, a batch of merges per launch.
@@ -1300,9 +1312,10 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             // plenty -- less to initialise and to flush; the count of the LAST batch's merges bounds this batch's)
             if (optv(c, "agg_small", 1) && !c->weighted && c->st_host->best_count * 4 < 48ull * std::max<uint32_t>(1u, c->n_cu * 3))
                 P.agg_mask = (uint32_t)(c->kmax_now > 2 ? AGG_N : nw >= 16 ? AGG_N / 2 : AGG_N / 4) - 1u;
-            ScanSkipParams SQ{P, c->blk_read, scan_grid, kt, chunk, R, fuse_params(scan_grid)};
+            const uint32_t rr_blocks = rank_rides ? rank_blocks : 0u;
+            ScanSkipParams SQ{P, c->blk_read, scan_grid, kt, chunk, R, fuse_params(scan_grid), LW, scan_grid + rr_blocks};
             c->blk_used = std::max(c->blk_used, scan_grid);
-            const uint32_t grid = scan_grid + (rank_rides ? rank_blocks : 0u);
+            const uint32_t grid = scan_grid + rr_blocks + long_blocks;
 #define YB_LAUNCH_SPARSE(NW_)                                                                                        \
     do {                                                                                                             \
         if (c->weighted)                                                                                             \
@@ -1321,10 +1334,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
-    if (!fuse_kernel && c->n_long) {
-        LongParams L{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
-        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, L);
-    }
+    if (!fuse_kernel && c->n_long) hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, LW);
     if (c->multi) {
         // Per batch: the apply launch above left this rank's updates as [header | records] in its send buffer (the
         // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every
@@ -1386,6 +1396,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     h->halt = 0;
     h->halt_req = 0;
     h->n_batch = 0;
+    h->batch_others = 0;
     h->kmax = 1;
     h->win_shift = 3;
     TRY(state_push(c));
@@ -1449,7 +1460,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     bool skip_cand_once = false;
     bool first_round = true;
     unsigned long long prev_best = 0;
-    uint64_t launches_sparse = 0;
+    uint64_t launches_sparse = 0, launches_at_tail = 0;
     uint32_t cand_n_all = 0;  // length of the candidate list at the last read (multi-GPU: of the longest replica's)
     bool sparse_global = false;  // the sparse form has been called for (by any rank)
     c->use_cand = false;
@@ -1474,6 +1485,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         if (!tail_marked && i >= num_merges / 2) {  // (measurement: the second half of this call's merges)
             tail_marked = true;
             tail_at = i;
+            launches_at_tail = launches_sparse;
             HIPCHK(c, hipEventRecord(T.t_tail, c->stream));
         }
         if (c->split_mode && !split_marked) {  // (measurement: where the streaming phase ends and the sparse phase begins)
@@ -1678,6 +1690,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         HIPCHK(c, hipEventElapsedTime(&tms, T.t_tail, T.t1));
         c->stats.tail_ms += tms;
         c->stats.tail_merges += (h->iter - rec_base) > tail_at ? (h->iter - rec_base) - tail_at : 0;
+        c->stats.tail_launches += launches_sparse - launches_at_tail;
     }
     c->stats.train_ms += ms;
 

@@ -33,7 +33,7 @@ constexpr int BLOCK = WPB * 64;
 constexpr int AGG_N = 1024;          // LDS delta-aggregator entries per workgroup
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PADPAD = (YB_PAD << 16) | YB_PAD;
-constexpr int LONG_CH = 4096;        // long-word path: tokens per LDS chunk
+constexpr int LONG_CH = 1024;        // long-word path: tokens per LDS chunk (the block rides on the per-batch launches: its LDS counts against theirs)
 constexpr int SIG_ROWS = 512;        // tile signature: a blocked Bloom filter of the adjacent pairs present in the tile --
 constexpr int SIG_ROWS_LOG2 = 9;     // 512 blocks of 64 bits (4 KiB per tile); a pair owns 3 bits inside ONE block
 constexpr int SIG_TILES = 8;         // k_build_sig: tiles whose signatures one workgroup transposes together (64-B rows)
@@ -44,7 +44,7 @@ constexpr int scan_kt_max(int nw) { return nw >= 16 ? 2 : 4; } // (a workgroup's
 
 enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
 
-constexpr int KMAX = 8; // merges one sparse launch applies at most (a batch, see select_batch)
+constexpr int KMAX = 16; // merges one sparse launch applies at most (a batch, see select_batch)
 struct BatchMerge {
     uint32_t a, b, c, is_new; // the pair, the merged token, whether the merge created it
 };
@@ -71,6 +71,7 @@ struct DevState {
     uint32_t win_shift;            // the selection's window takes the pairs with count >= max - (max >> win_shift); it adapts the shift to
                                    // what it finds (few pairs: wider, more than fit: narrower) -- from counts and distinct pairs only, so
                                    // every rank of a multi-GPU job keeps the same value
+    unsigned long long batch_others; // sum of the counts of batch[0 .. n_batch - 1): the sites those merges have in the flat layout
     uint32_t n_batch;              // merges selected and not applied yet: batch[0 .. n_batch), in selection order; a, b, c above = batch[0]
     BatchMerge batch[KMAX];
 };
@@ -406,6 +407,14 @@ __device__ __forceinline__ void agg_add_wave(Agg<int> g, const PairTable &t, Dev
     if (valid) agg_add(g, t, st, key, (long long)sign);
 }
 
+// LDS scratch discipline (audited after the race of e85c033).  A __device__ helper that declares its own __shared__ scratch is
+// either called once per workgroup and kernel (rank_update_block, fold_block_stats, last_workgroup, select_body, select_eval: their
+// first use of the scratch sits behind a barrier of their own) or may be called back to back -- flush_entries' record sink, once per
+// role from hist_flush -- and then ENDS on a barrier, so that no wave can rewrite the scratch while a slower one still reads it.
+// Helpers that work on the caller's LDS (agg_add / agg_flush, apply_epilogue, slow_tile on a wave's WaveLds) rely on the caller:
+// a __syncthreads() between the last add and the flush (apply_epilogue has one), wave_sync() between a wave's own LDS phases.
+// tests/test_gpu_distributed.py::test_four_ranks_direct_store_flushes_into_the_send_buffer is the case that exposed the race.
+//
 // get(i) -> FlushEnt: entry i of the workgroup's delta store (key EMPTY or val 0: nothing); N_ENT entries, NT threads.
 struct FlushEnt {
     uint32_t key;
@@ -1490,7 +1499,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_sig_long(LongParams P) {
 // (ONE 8-byte load per word -- a merge whose pair occurs in no long word costs a launch of n_long / 256 workgroups that
 // read 8 bytes per word and leave), the words that pass are rewritten one after the other by the whole workgroup
 // (sequential greedy rewrite in chunks, thread 0 carries the state across chunks; the pairs it creates set their bits).
-__global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
+__device__ __forceinline__ void apply_long_block(const LongParams &P, uint32_t block) { // BLOCK threads; block = which BLOCK words
     __shared__ uint16_t s_in[LONG_CH + 4];
     __shared__ uint16_t s_o[LONG_CH];
     __shared__ uint32_t s_j, s_o_pos, s_adv, s_nout, s_nhit;
@@ -1505,7 +1514,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     {
-        const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+        const uint32_t i = block * BLOCK + threadIdx.x;
         bool maybe = i < P.n_long;
         if (maybe && P.sig) {
             const SigHash H = sig_hash(self);
@@ -1591,6 +1600,16 @@ __global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) {
     __syncthreads();
     }
     }
+}
+__global__ __launch_bounds__(BLOCK) void k_apply_long(LongParams P) { apply_long_block(P, blockIdx.x); }
+
+// lengths of the long words (bytes = tokens at load), for the prefix sum that places them in their buffer
+__global__ void k_long_lengths(const unsigned long long *off, const uint32_t *long_word, uint32_t n_long, uint32_t *out_len, uint32_t *too_long) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    const unsigned long long L = off[long_word[i] + 1] - off[long_word[i]];
+    if (L > 0xFFFFFFFFull) atomicExch(too_long, 1u);
+    out_len[i] = (uint32_t)L;
 }
 
 // ================================================================ argmax (trainer.py:246)
@@ -1855,8 +1874,8 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
     DevState *st = P.st;
     const int tid = threadIdx.x;
     YB_SEL_STAMP(1);
-    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0, d_prev_batch = 0;
-    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0;
+    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0;
+    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0, d_prev_others = 0;
     unsigned long long candT = 0;
     uint32_t cand_over = 0, cand_n = 0;
     if (tid == 0) {
@@ -1869,7 +1888,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
         d_min_freq = st->min_freq;
         d_live_slots = st->live_slots;
         d_tokens_now = st->tokens_now;
-        d_prev_batch = st->n_batch;
+        d_prev_others = st->batch_others;
         // fields other workgroups of this launch may have moved (atomics): read them past the caches
         d_halt_req = ld_coherent(&st->halt_req);
         d_table_entries = ld_coherent(&st->table_entries);
@@ -1937,16 +1956,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
             // left.  (Pooled words / several ranks: counts are not resident sites; the whole batch is logged on its last merge.)
             const uint32_t it = d_iter;
             if (it > P.rec_base && d_sites) { // (0: already closed, this is a re-run)
-                const uint32_t pb = min(max(d_prev_batch, 1u), it - P.rec_base);
-                unsigned long long others = 0;
-                if (P.flat_single)
-                    for (uint32_t m = it - pb; m + 1 < it; ++m) others += P.rec_count[m - P.rec_base];
-                if (others <= d_sites && P.flat_single) {
-                    for (uint32_t m = it - pb; m + 1 < it; ++m) P.rec_sites[m - P.rec_base] = P.rec_count[m - P.rec_base];
-                    P.rec_sites[it - 1 - P.rec_base] = d_sites - others;
-                } else {
-                    P.rec_sites[it - 1 - P.rec_base] = d_sites;
-                }
+                // (the batch's other merges were logged with their counts when they were selected: what is left is the last one's)
+                const unsigned long long others = P.flat_single ? d_prev_others : 0ull;
+                P.rec_sites[it - 1 - P.rec_base] = others <= d_sites ? d_sites - others : d_sites;
             }
             d_tokens_now -= d_sites;
             d_sites = 0;
@@ -2068,6 +2080,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
             st->c_is_new = is_new;
             st->batch[0] = BatchMerge{x, y, cid, is_new};
             st->n_batch = 1u;
+            st->batch_others = 0ull;
             st->iter = d_iter + 1;
             st->pool_used = is_new ? ((pu + L + 3u) & ~3u) : pu;
             st->n_tokens = d_n_tokens + is_new;
@@ -2103,8 +2116,8 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     for (int k = 0; k < 4; ++k) e[k] = ld_coherent(&P.table.cand_list[tid + k * BLOCK]);
     const uint32_t n_list = min(ld_coherent(&P.cs->n), CAND_CAP);
     const uint32_t kmax = min(st->kmax, (uint32_t)KMAX);
-    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0, d_prev_batch = 0;
-    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0, candT = 0;
+    uint32_t d_iter = 0, d_done = 0, d_halt = 0, d_halt_req = 0, d_n_tokens = 0, d_pool_used = 0, d_num_merges = 0;
+    unsigned long long d_min_freq = 0, d_table_entries = 0, d_live_slots = 0, d_sites = 0, d_tokens_now = 0, candT = 0, d_prev_others = 0;
     uint32_t cand_over = 0, cand_n = 0;
     if (tid == 0) {
         d_iter = st->iter;
@@ -2116,7 +2129,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         d_min_freq = st->min_freq;
         d_live_slots = st->live_slots;
         d_tokens_now = st->tokens_now;
-        d_prev_batch = st->n_batch;
+        d_prev_others = st->batch_others;
         d_halt_req = ld_coherent(&st->halt_req);
         d_table_entries = ld_coherent(&st->table_entries);
         d_sites = ld_coherent(&st->sites);
@@ -2348,16 +2361,9 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
             // close the log entries of the batch that has just been applied (see select_body)
             const uint32_t it = d_iter;
             if (it > P.rec_base && d_sites) {
-                const uint32_t pb = min(max(d_prev_batch, 1u), it - P.rec_base);
-                unsigned long long others = 0;
-                if (P.flat_single)
-                    for (uint32_t m = it - pb; m + 1 < it; ++m) others += P.rec_count[m - P.rec_base];
-                if (others <= d_sites && P.flat_single) {
-                    for (uint32_t m = it - pb; m + 1 < it; ++m) P.rec_sites[m - P.rec_base] = P.rec_count[m - P.rec_base];
-                    P.rec_sites[it - 1 - P.rec_base] = d_sites - others;
-                } else {
-                    P.rec_sites[it - 1 - P.rec_base] = d_sites;
-                }
+                // (the batch's other merges were logged with their counts when they were selected: what is left is the last one's)
+                const unsigned long long others = P.flat_single ? d_prev_others : 0ull;
+                P.rec_sites[it - 1 - P.rec_base] = others <= d_sites ? d_sites - others : d_sites;
             }
             d_tokens_now -= d_sites;
             d_sites = 0;
@@ -2483,6 +2489,12 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     if ((uint32_t)lane < nacc && (ntok0 + (uint32_t)lane >= YB_MAX_TOKENS || (unsigned long long)pool_at + Lk + 4ull > P.tt.pool_cap)) bad = 1u;
     const unsigned long long badm = __ballot(bad != 0u);
     const uint32_t keep = badm ? (uint32_t)(__ffsll((long long)badm) - 1) : nacc; // merges [0, keep) are committed here
+    // (sum of the counts of the merges in front of the last one: a few lanes)
+    unsigned long long others_sum = 0ull;
+    {
+        const unsigned long long mycnt = (uint32_t)lane + 1u < keep ? s_win[wk].cnt : 0ull;
+        others_sum = wave_sum_u64(mycnt);
+    }
     if ((uint32_t)lane < keep) { // commit merge k = lane
         const uint32_t k = (uint32_t)lane;
         const uint32_t cid = ntok0 + k, key = s_win[wk].key;
@@ -2495,6 +2507,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         P.rec_right[ri] = key & 0xffffu;
         P.rec_merged[ri] = cid;
         P.rec_count[ri] = s_win[wk].cnt;
+        if (P.flat_single && k + 1u < keep) P.rec_sites[ri] = s_win[wk].cnt; // flat layout, a != b: a merge's sites are exactly its count (the last merge of the batch gets what is left, next time)
         P.rec_live_slots[ri] = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(d_live_slots >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d_live_slots);
         // after the merge no (x, y) adjacency is left anywhere (trainer.py:276-285), so its count is exactly 0: set it here once
         // instead of letting every workgroup subtract its share from one hot address
@@ -2511,6 +2524,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
             st->n_tokens = cid + 1u;
             st->iter = it0 + keep;
             st->n_batch = keep;
+            st->batch_others = others_sum;
             st->best_count = s_win[wk].cnt; // (the host's heuristics look at the lowest count selected so far)
 #ifdef YB_PROFILE_LAUNCH
             g_launch_prof[(it0 & 0xFFFFu) * 4 + 3] = wall_clock64(); // (same index as the launch that ran this selection: its st->iter at start)
@@ -2581,6 +2595,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
                 st->best_count = s_win[w].cnt;
                 st->batch[0] = BatchMerge{x, y, cid, is_new};
                 st->n_batch = 1u;
+                st->batch_others = 0ull;
                 st->iter = it0 + 1u;
                 st->pool_used = is_new ? ((pool0 + Lm + 3u) & ~3u) : pool0;
                 st->n_tokens = ntok0 + is_new;
@@ -2802,7 +2817,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
 // (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
 // HIST (flat layout, at most HIST_V tokens): the deltas go to the direct-indexed LDS store (Hist) instead of the hashed one.
 template <bool WEIGHTED, bool HIST = false>
-__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F) {
+__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F, LongParams LW, uint32_t long_first) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     static_assert(!(HIST && WEIGHTED), "the direct-indexed store holds 32-bit deltas");
     __shared__ uint32_t s_keys[HIST ? 1 : AGG_N];
@@ -2813,8 +2828,11 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
 
     DevState *st = P.st;
     if (st->done | st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
-    // workgroups [0, apply_blocks) apply the merge; the rest of the grid does k_rank_update's work in the same launch
-    if (blockIdx.x >= apply_blocks) {
+    // workgroups [0, apply_blocks) apply the merge; [apply_blocks, long_first) do k_rank_update's work and [long_first, ..) the
+    // long words' (k_apply_long) in the same launch
+    if (blockIdx.x >= long_first) {
+        apply_long_block(LW, blockIdx.x - long_first);
+    } else if (blockIdx.x >= apply_blocks) {
         rank_update_block(R, blockIdx.x - apply_blocks);
     } else {
     const int lane = threadIdx.x & 63;
@@ -2913,6 +2931,8 @@ struct ScanSkipParams {
                                   // -- pooled words -- still spreads over 125 workgroups whose waves ALL rewrite matched tiles)
     RankParams R;                 // (lexrank maintenance is independent of the scan: same launch, no extra boundary)
     FuseParams F;                 // ticket != NULL: the workgroup that finishes last selects the next batch
+    LongParams LW;                // the long words ride along too: workgroups [long_first, gridDim.x) (k_apply_long's work)
+    uint32_t long_first;
 };
 
 // what a workgroup keeps about the merges of the batch (LDS)
@@ -2966,8 +2986,11 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
     YB_LAUNCH_START(prof_it);
 #endif
     if (blockIdx.x >= Q.scan_blocks) {
-        if (NW > WPB && threadIdx.x >= BLOCK) return false; // (lexrank maintenance is written for BLOCK threads: the other waves end here)
-        rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
+        if (NW > WPB && threadIdx.x >= BLOCK) return false; // (lexrank maintenance and the long words are written for BLOCK threads: the other waves end here)
+        if (blockIdx.x >= Q.long_first)
+            apply_long_block(Q.LW, blockIdx.x - Q.long_first);
+        else
+            rank_update_block(Q.R, blockIdx.x - Q.scan_blocks);
         YB_SCAN_STAMP(7);
         YB_LAUNCH_END(prof_it);
         return true;
@@ -3085,7 +3108,9 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
         }
         __syncthreads();
         YB_SCAN_STAMP(2);
-        YB_SCAN_STAMP(3);
+#ifdef YB_PROFILE_SCAN
+        if (threadIdx.x == 0 && blockIdx.x < MAX_LISTS_PROF) g_scan_prof[blockIdx.x * 8 + 3] = ((unsigned long long)nbatch << 32) | n; // (merges of this launch, candidate tiles of this workgroup)
+#endif
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     }
