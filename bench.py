@@ -132,7 +132,7 @@ def main() -> None:
         from yet_another_bpe import distributed as ydist
 
         runner = ydist.ShardedRunner(gen, pb, po, n_words, n_bytes, base, rank, world, local_rank,
-                                     transport="torch" if rehearsal else "rccl")
+                                     transport=("torch" if rehearsal else "rccl") + ("" if os.environ.get("YABPE_P2P") == "0" else "+p2p"))
         runner._context()  # rendezvous + RCCL communicator before the timed region
     else:
         runner = None
@@ -197,8 +197,13 @@ def main() -> None:
         out["exchange"] = {"all_gathers": st["exchanges"], "bytes_received_per_merge": st["exchange_bytes"], "record_capacity_per_rank": st["exchange_cap_records"],
                            "buffer_growths": st["exchange_growths"], "max_records_of_a_rank_at_a_batch_end": st["exchange_max_records"],
                            "merges_per_exchange": round(n_merges / max(1, st["exchanges"]), 2),
-                           "note": "per batch of merges: apply launch (deltas leave as records) -> one all-gather of [header | records] -> one launch that adds "
-                                   "every rank's records to the replica and selects the next batch"}
+                           "peer_to_peer": bool(st["exchange_p2p"]),
+                           "exchange_launch_us_sampled": round(1e3 * st["exchange_ms_sampled"] / st["exchanges_sampled"], 2) if st["exchanges_sampled"] else None,
+                           "note": "per batch of merges: apply launch (deltas leave as records) -> the exchange -> one launch that adds every rank's records "
+                                   "to the replica and selects the next batch.  peer_to_peer: the exchange is ONE small launch that pushes this rank's "
+                                   "records into the peers' hipIpc-mapped buffers (xGMI), raises a flag there and waits for theirs "
+                                   "(exchange_launch_us_sampled: its device time, one per round of launches, waiting for the slowest peer included); "
+                                   "otherwise an RCCL all-gather of [header | records] on the compute stream (YABPE_P2P=0, or a rank could not map a peer)"}
     # ---- what bounds the timed job.  It has two phases:
     #   streaming (the first few hundred merges, most tiles change): ONE fused launch per merge, k_apply -- a coalesced read of
     #   the whole live token stream + rewrite + pair-table update + the selection of the next merge.  HBM-bound by design:

@@ -136,6 +136,10 @@ typedef struct yabpe_stats_t {
     uint64_t sparse_launches;
     /* ... and the launches of the second half of each yabpe_train call's merges (tail_merges / tail_launches = mean batch there) */
     uint64_t tail_launches;
+    /* peer-to-peer exchange: device time of the event-timed push-and-wait launches (one per round of launches) */
+    double exchange_ms_sampled;
+    uint64_t exchanges_sampled;
+    uint64_t exchange_p2p;     /* 1: the exchanges go peer to peer (0: through the attached transport's all-gather) */
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */
@@ -212,6 +216,14 @@ int yabpe_comm_init(yabpe_ctx *ctx, int rank, int n_ranks, const uint8_t unique_
  * order) and return 0; it is called with the context's stream idle. */
 typedef int (*yabpe_allgather_fn)(void *user, const void *send_dev, void *recv_dev, uint64_t nbytes);
 int yabpe_comm_init_custom(yabpe_ctx *ctx, int rank, int n_ranks, yabpe_allgather_fn fn, void *user);
+/* Peer-to-peer exchange instead of the all-gather (after yabpe_comm_init / yabpe_comm_init_custom, before yabpe_load_words;
+ * collective: every rank calls it).  Each rank exports its receive area as a hipIpc handle (the attached transport carries
+ * the 64-byte handles once), maps its peers' areas, and from then on every exchange is ONE small launch that pushes this
+ * rank's records into the peers' memory (xGMI between GPUs of a node; two processes on one GPU work the same way), raises a
+ * flag there and waits for the peers' flags -- no collective kernel, no host in the loop.  The transport stays attached
+ * for the rare small agreements (lockstep check, buffer growth).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the host
+ * driver only supports dmabuf IPC. */
+int yabpe_comm_enable_p2p(yabpe_ctx *ctx);
 
 #ifdef __cplusplus
 }

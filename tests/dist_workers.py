@@ -154,7 +154,7 @@ def cpu_sharded_reference(rank, world, dist, words_hex, specials, vocab_size, mi
 
 
 # ---------------------------------------------------------------- GPU: 2 ranks on one GPU through the custom transport
-def gpu_sharded(rank, world, dist, scenario):
+def gpu_sharded(rank, world, dist, scenario, transport="torch"):
     import numpy as np
 
     from tests import helpers
@@ -193,7 +193,9 @@ def gpu_sharded(rank, world, dist, scenario):
     else:
         raise ValueError(scenario)
     left, right, merged, count, stats = train_sharded(lambda: _native.Context(0), flat, off, freq, base, merges, 1, rank, world,
-                                                      transport="torch", options=opts)
+                                                      transport=transport, options=opts)
+    if transport.endswith("+p2p"):
+        assert stats["exchange_p2p"] == 1 and stats["exchanges_sampled"] > 0  # the exchanges really went peer to peer
     toks = list(base)
     out = []
     for l, r, m in zip(left.tolist(), right.tolist(), merged.tolist()):
@@ -214,7 +216,7 @@ def gpu_text_sharded(rank, world, dist, path, chunk_size, vocab_size, specials):
     return [(a.hex(), b.hex()) for a, b in model.merges], len(model.vocab)
 
 
-def gpu_fullsize_sharded(rank, world, dist):
+def gpu_fullsize_sharded(rank, world, dist, transport="torch"):
     """BASELINE configs[3]: the 1 GiB / 32,000-merge job word-sharded over `world` ranks that share the test box's one GPU
     (custom transport, gloo underneath).  Every rank generates the corpus on the device, trains on its word range and
     returns the digest of its (left, right, merged) id triples, its merge count and the corpus digest inputs."""
@@ -230,7 +232,7 @@ def gpu_fullsize_sharded(rank, world, dist):
     base = helpers.base_tokens(["<|endoftext|>"])
     with _native.Context(0) as gen:
         pb, po, nw, nb = gen.synth_generate(spec.target_bytes, spec.n_types, spec.seed, spec.alphabet, spec.space_prefix)
-        runner = ShardedRunner(gen, pb, po, nw, nb, base, rank, world, 0, transport="torch")
+        runner = ShardedRunner(gen, pb, po, nw, nb, base, rank, world, 0, transport=transport)
         try:
             res = runner.run(32000, 1)
             mism = runner._ctx.verify_table()
@@ -238,7 +240,8 @@ def gpu_fullsize_sharded(rank, world, dist):
             runner.close()
     h = hashlib.sha256(res["left"].astype(np.uint32).tobytes() + res["right"].astype(np.uint32).tobytes() + res["merged"].astype(np.uint32).tobytes()).hexdigest()
     st = res["stats"]
-    return h, int(res["n_merges"]), int(nw), int(nb), int(mism), int(st["n_words"]), int(st["exchanges"]), int(st["exchange_growths"])
+    xus = 1e3 * st["exchange_ms_sampled"] / max(1, st["exchanges_sampled"]) if st["exchange_p2p"] else -1.0
+    return h, int(res["n_merges"]), int(nw), int(nb), int(mism), int(st["n_words"]), int(st["exchanges"]), int(st["exchange_growths"]), float(xus), float(st["train_ms"])
 
 
 def gpu_device_text_sharded(rank, world, dist, meta_name, n_merges=None):

@@ -60,18 +60,20 @@ def test_config3_one_gib_32k_merges(golden_dir):
         assert triples[0] == triples[1] == triples[2] == meta["id_triples_sha256"]  # layouts and repeated runs agree with the oracle
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_config4_one_gib_word_sharded(golden_dir, world):
+@pytest.mark.parametrize("world,transport", [(2, "torch"), (2, "torch+p2p"), (4, "torch+p2p")])
+def test_config4_one_gib_word_sharded(golden_dir, world, transport):
     """BASELINE configs[3]: the same job word-sharded over 2 and 4 ranks (they share the test box's one GPU and exchange
     through the custom transport; the exchange protocol, the replicated table and the batch selection are what RCCL ranks
     run too).  Every rank must return the oracle's id triples (G7), hold a consistent table and a share of the words."""
     from tests import dist_workers
 
     meta = json.loads((golden_dir / "g7_config3_meta.json").read_text())
-    outs = dist_workers.spawn(dist_workers.gpu_fullsize_sharded, world, timeout=1500)
-    for digest, n_merges, nw, nb, mism, my_words, exchanges, growths in outs:
+    # ("torch": every exchange is an all-gather through host memory (gloo); "+p2p": the ranks push their records into each
+    # other's hipIpc-mapped buffers from a kernel -- what GPUs of one node do over xGMI)
+    outs = dist_workers.spawn(dist_workers.gpu_fullsize_sharded, world, transport, timeout=1500)
+    for digest, n_merges, nw, nb, mism, my_words, exchanges, growths, xus, train_ms in outs:
         assert (nb, nw) == (meta["corpus_bytes"], meta["n_words"])
         assert n_merges == meta["n_merges"] and digest == meta["id_triples_sha256"]
         assert mism == 0 and my_words > 0 and exchanges > 0
     assert sum(o[5] for o in outs) == meta["n_words"]  # the shards cover the corpus exactly once
-    print("world", world, "exchanges", outs[0][6], "buffer growths", outs[0][7])
+    print("world", world, transport, "exchanges", outs[0][6], "buffer growths", outs[0][7], "exchange launch us (sampled)", round(outs[0][8], 2), "merge loop ms", round(outs[0][9], 1))

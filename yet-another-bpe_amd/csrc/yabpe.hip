@@ -189,6 +189,13 @@ struct yabpe_ctx {
     uint64_t xeff_sum = 0;  // (statistics: sum of xeff over the exchanges)
     uint32_t xseen[4] = {0, 0, 0, 0};  // the largest record counts of the last four batches
     uint64_t exchanges = 0;
+    // peer-to-peer exchange (yabpe_comm_enable_p2p): receive areas mapped through hipIpc handles
+    bool p2p = false;
+    uint8_t *p2p_area = nullptr;               // this rank's receive area: 2 halves of n_ranks slots + the flag words (plain hipMalloc: exported)
+    std::vector<uint8_t *> p2p_peer;           // every rank's area as mapped here (own rank: p2p_area)
+    uint64_t p2p_half = 0, p2p_flags_off = 0, p2p_seq = 0;
+    hipEvent_t p2p_e0 = nullptr, p2p_e1 = nullptr;  // (statistics: every 64th exchange is timed)
+    bool p2p_pending = false;                  // an event pair was recorded and not read yet
 };
 
 namespace {
@@ -694,6 +701,66 @@ int table_grow(yabpe_ctx *c, uint64_t new_cap) {
     return fail(c, YABPE_E_CAPACITY, "pair table does not fit");
 }
 
+void p2p_close(yabpe_ctx *c) {
+    for (size_t r = 0; r < c->p2p_peer.size(); ++r)
+        if (c->p2p_peer[r] && (int)r != c->rank) (void)hipIpcCloseMemHandle(c->p2p_peer[r]);
+    c->p2p_peer.clear();
+    if (c->p2p_area) (void)hipFree(c->p2p_area);
+    c->p2p_area = nullptr;
+}
+
+// (Re)build the peer-to-peer receive areas for the current buffer geometry: allocate, exchange the IPC handles through the
+// attached transport (one all-gather of 64 bytes per rank), map the peers' areas.  Collective: every rank calls it at the same
+// point and runs the same sequence of collectives whatever fails locally; if ANY rank could not export or map a buffer, all
+// ranks drop the peer-to-peer path together and keep exchanging through the transport (c->p2p = false, no error).
+int p2p_setup(yabpe_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    p2p_close(c);
+    unsigned long long failed = 0;
+    std::string why;
+    if (c->n_ranks > XCHG_MAX_RANKS) { failed = 1; why = "too many ranks"; }
+    c->p2p_half = c->xstride * (uint64_t)c->n_ranks;
+    c->p2p_flags_off = (2 * c->p2p_half + 255) & ~255ull;
+    const uint64_t bytes = c->p2p_flags_off + 2ull * c->n_ranks * 8 + 256;
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof mine);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (!failed) {
+        hipError_t e = hipMalloc((void **)&c->p2p_area, bytes);
+        if (e == hipSuccess) e = hipMemset(c->p2p_area, 0, bytes);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&mine, c->p2p_area);
+        if (e != hipSuccess) { failed = 1; why = std::string("export: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+    }
+    uint8_t *d_h = nullptr, *d_all = nullptr;
+    TRY(dmalloc(c, &d_h, 64));
+    TRY(dmalloc(c, &d_all, 64ull * c->n_ranks));
+    HIPCHK(c, hipMemcpy(d_h, &mine, 64, hipMemcpyHostToDevice));
+    TRY(comm_allgather(c, d_h, d_all, 64));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<hipIpcMemHandle_t> all(c->n_ranks);
+    HIPCHK(c, hipMemcpy(all.data(), d_all, 64ull * c->n_ranks, hipMemcpyDeviceToHost));
+    dfree(d_h);
+    dfree(d_all);
+    c->p2p_peer.assign(c->n_ranks, nullptr);
+    for (int r = 0; r < c->n_ranks && !failed; ++r) {
+        if (r == c->rank) { c->p2p_peer[r] = c->p2p_area; continue; }
+        void *q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, all[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { failed = 1; why = std::string("map: ") + hipGetErrorString(e); (void)hipGetLastError(); break; }
+        c->p2p_peer[r] = (uint8_t *)q;
+    }
+    c->p2p_seq = 0;
+    // nobody pushes before every rank has mapped everything -- and everybody learns whether somebody could not
+    unsigned long long any_failed = 0;
+    TRY(comm_max(c, failed, &any_failed));
+    if (any_failed) {
+        p2p_close(c);
+        c->p2p = false;
+        if (failed && optv(c, "trace_exchange", 0)) fprintf(stderr, "[yabpe r%d] peer-to-peer exchange not available here (%s): exchanging through the transport\n", c->rank, why.c_str());
+    }
+    return 0;
+}
+
 // (re)allocate the per-iteration exchange buffers for `cap` records per rank
 int comm_buffers(yabpe_ctx *c, uint32_t cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -707,6 +774,7 @@ int comm_buffers(yabpe_ctx *c, uint32_t cap) {
     TRY(dmalloc(c, &c->xrecv, c->xstride * c->n_ranks));
     HIPCHK(c, hipMemsetAsync(c->xsend, 0, c->xstride, c->stream));
     HIPCHK(c, hipMemsetAsync(c->xrecv, 0, c->xstride * c->n_ranks, c->stream));
+    if (c->p2p) TRY(p2p_setup(c));  // (the slots have a new size: new areas, new handles -- every rank is here together)
     return 0;
 }
 
@@ -895,6 +963,9 @@ void yabpe_destroy(yabpe_ctx *c) {
     dfree(c->xsend);
     dfree(c->xrecv);
     dfree(c->xsmall);
+    p2p_close(c);
+    if (c->p2p_e0) (void)hipEventDestroy(c->p2p_e0);
+    if (c->p2p_e1) (void)hipEventDestroy(c->p2p_e1);
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->st_host) (void)hipHostFree(c->st_host);
     for (auto &e : c->events) {
@@ -1172,6 +1243,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.tail_ms = 0;
     c->stats.tail_merges = 0;
     c->stats.tail_launches = 0;
+    c->stats.exchange_ms_sampled = 0;
+    c->stats.exchanges_sampled = 0;
     c->stats.scan_ms_sampled = 0;
     c->stats.scan_launches_sampled = 0;
     c->stats.scan_algo_bytes_sampled = 0;
@@ -1340,9 +1413,35 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every
         // rank's records to the replica and -- fused form -- selects the next merges in its last workgroup.
         const uint64_t xbytes = 16 + (uint64_t)c->xeff * sizeof(DeltaRec);  // [header | xeff records] per rank, packed at that stride
-        TRY(comm_allgather(c, c->xsend, c->xrecv, xbytes));
+        const uint8_t *recv = c->xrecv;
+        uint64_t rstride = xbytes;
+        if (c->p2p) {  // push into the peers' memory, wait for theirs: one small launch, no collective
+            XchgParams X{};
+            X.send = c->xsend;
+            for (int r = 0; r < c->n_ranks; ++r) X.peer[r] = c->p2p_peer[r];
+            X.flags_off = c->p2p_flags_off;
+            X.half_bytes = c->p2p_half;
+            X.stride = c->xstride;
+            X.seq = ++c->p2p_seq;
+            X.rank = (uint32_t)c->rank;
+            X.n_ranks = (uint32_t)c->n_ranks;
+            X.cap = c->xeff;
+            X.timeout_ticks = (unsigned long long)optv(c, "p2p_timeout_ms", 20000) * 100000ull;
+            X.st = c->st;
+            const bool timed = !c->p2p_pending && c->p2p_e0;  // (one exchange per round of launches is timed)
+            if (timed) HIPCHK(c, hipEventRecord(c->p2p_e0, c->stream));
+            hipLaunchKernelGGL(k_xchg_push, dim3((uint32_t)c->n_ranks), dim3(BLOCK), 0, c->stream, X);
+            if (timed) {
+                HIPCHK(c, hipEventRecord(c->p2p_e1, c->stream));
+                c->p2p_pending = true;  // (read at the end of this round of launches)
+            }
+            recv = c->p2p_area + (X.seq & 1ull) * c->p2p_half;
+            rstride = c->xstride;
+        } else {
+            TRY(comm_allgather(c, c->xsend, c->xrecv, xbytes));
+        }
         c->xeff_sum += c->xeff;
-        DeltaApplyParams DA{c->xrecv, (uint32_t)c->n_ranks, c->xeff, xbytes, c->table, c->st, FuseParams{}};
+        DeltaApplyParams DA{recv, (uint32_t)c->n_ranks, c->xeff, rstride, c->table, c->st, FuseParams{}, c->p2p ? 1u : 0u};
         if (fuse) {
             DA.F.ticket = c->sel_ticket;
             DA.F.sel = select_params(c, rec_base, 0u, c->blk_used);
@@ -1587,6 +1686,16 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         TRY(fold_stats(c));
         TRY(state_pull(c));
         i = h->iter - rec_base;                              // what the device really selected
+        if (c->p2p_pending) {  // (the stream is idle: the pair has completed)
+            float xms = 0;
+            if (hipEventElapsedTime(&xms, c->p2p_e0, c->p2p_e1) == hipSuccess) {
+                c->stats.exchange_ms_sampled += xms;
+                c->stats.exchanges_sampled += 1;
+            } else {
+                (void)hipGetLastError();
+            }
+            c->p2p_pending = false;
+        }
         if (h->halt_req && !h->halt) h->halt = h->halt_req;  // raised by the last apply of the batch
         if (h->done || h->halt) c->pending = false;          // the last selection of the batch did not select
         if (c->multi && c->xrecv) {
@@ -1654,6 +1763,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;
                 continue;
             }
+            if (h->halt == HALT_COMM) return fail(c, YABPE_E_COMM, "a peer's records did not arrive within the time limit (peer-to-peer exchange) after %u merges", h->iter - rec_base);
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
                               : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
                                                            : "device halt";
@@ -1802,6 +1912,7 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
     c->stats.exchanges = c->exchanges;
     c->stats.exchange_bytes = (c->multi && c->exchanges) ? (16 + (c->xeff_sum / c->exchanges) * sizeof(DeltaRec)) * (uint64_t)c->n_ranks : 0;  // (mean over the exchanges)
     c->stats.exchange_cap_records = c->xcap;
+    c->stats.exchange_p2p = c->p2p ? 1 : 0;
     c->stats.exchange_growths = c->exchange_growths;
     c->stats.exchange_max_records = c->exchange_max_records;
     c->stats.scan_skip_launches = c->scan_skip_launches;
@@ -2160,6 +2271,19 @@ int yabpe_comm_init(yabpe_ctx *c, int rank, int n_ranks, const uint8_t unique_id
     memcpy(&id, unique_id, 128);
     NCCLCHK(c, R->CommInitRank(&c->comm, n_ranks, id, rank));
     return comm_finish(c);
+}
+
+int yabpe_comm_enable_p2p(yabpe_ctx *c) {
+    if (!c) return YABPE_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->multi) return YABPE_OK;  // one rank: nothing to exchange
+    if (c->have_words) return fail(c, YABPE_E_INVALID, "enable the peer-to-peer exchange before yabpe_load_words");
+    if (!c->p2p_e0) {
+        HIPCHK(c, hipEventCreate(&c->p2p_e0));
+        HIPCHK(c, hipEventCreate(&c->p2p_e1));
+    }
+    c->p2p = true;
+    return p2p_setup(c);
 }
 
 int yabpe_comm_init_custom(yabpe_ctx *c, int rank, int n_ranks, yabpe_allgather_fn fn, void *user) {

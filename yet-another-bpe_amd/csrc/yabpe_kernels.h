@@ -42,7 +42,7 @@ constexpr int SCAN_CHUNK = 256;      // k_scan_skip: consecutive tiles examined 
 constexpr int SCAN_KT_MAX = 4;       // ... kt <= 4 signature tests per thread, so that the whole grid is resident at once
 constexpr int scan_kt_max(int nw) { return nw >= 16 ? 2 : 4; } // (a workgroup's hit list lives in LDS: 64 * nw * kt entries)
 
-enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5 };
+enum : uint32_t { HALT_NONE = 0, HALT_TABLE_FULL = 1, HALT_POOL_FULL = 2, HALT_VOCAB_FULL = 3, HALT_DELTA_FULL = 4, HALT_RESCAN = 5, HALT_COMM = 6 };
 
 constexpr int KMAX = 16; // merges one sparse launch applies at most (a batch, see select_batch)
 struct BatchMerge {
@@ -3159,6 +3159,8 @@ struct DeltaApplyParams {
     PairTable table;
     DevState *st;
     FuseParams F;        // ticket != NULL: the workgroup that finishes last selects the next merge (one launch fewer per merge)
+    uint32_t peer_written; // the buffers were written by OTHER processes / devices (peer-to-peer exchange): read them past the caches --
+                           // this device's L2s may still hold the lines of the exchange before last
 };
 // Every rank's records name the same hot pairs over and over (one record per WORKGROUP of the sender that saw the pair, times
 // the number of ranks), and same-address atomics are served one per 12.5 ns: added to the table record by record they would
@@ -3178,21 +3180,77 @@ __global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
         const uint32_t r = (uint32_t)(idx / P.cap), j = (uint32_t)(idx % P.cap);
         if (r < P.n_ranks) {
             const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.recv + r * P.stride);
-            const unsigned long long n = h->count;
+            auto ld = [&](const void *q) -> unsigned long long {
+                unsigned long long *u = reinterpret_cast<unsigned long long *>(const_cast<void *>(q));
+                return P.peer_written ? __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *u;
+            };
+            const unsigned long long n = ld(&h->count), hhalt = ld(&h->halt);
             if (j == 0) { // every rank reads every header: all of them stop at the same merge
-                if (h->halt) atomicMax(&P.st->halt_req, (uint32_t)h->halt);
+                if (hhalt) atomicMax(&P.st->halt_req, (uint32_t)hhalt);
                 else if (n > P.cap) atomicMax(&P.st->halt_req, (uint32_t)HALT_DELTA_FULL);
                 atomicMax(&P.st->xmax, (uint32_t)min(n, 0xffffffffull)); // (every rank sees every header: the same value everywhere)
             }
             if (j < n && j < P.cap) {
                 const DeltaRec *rec = reinterpret_cast<const DeltaRec *>(h + 1);
-                agg_add(agg, P.table, P.st, rec[j].key, rec[j].delta);
+                const unsigned long long w0 = ld(&rec[j]), w1 = ld(reinterpret_cast<const unsigned long long *>(&rec[j]) + 1);
+                agg_add(agg, P.table, P.st, (uint32_t)w0, (long long)w1);
             }
         }
     }
     __syncthreads();
     agg_flush<unsigned long long, BLOCK>(agg, P.table, P.st);
     fused_select_tail(P.F);
+}
+
+// ---------------------------------------------------------------- peer-to-peer exchange (instead of the all-gather)
+// Every rank maps its peers' receive buffers (hipIpc handles; on one node the mapping goes over xGMI, two processes on ONE
+// device work the same way).  After the apply launch one small kernel PUSHES this rank's [header | records] into its slot of
+// every peer's buffer and then raises a flag there (sequence number of the exchange; release at system scope); the workgroup
+// that copies into the rank's own slot then waits until every peer's flag for this exchange has arrived in ITS memory.  When
+// the kernel has finished, everything the next launch (k_delta_apply) reads is in local memory: no collective, no host.
+// A rank pushes what it produced (<= cap records), not the whole buffer.  Two buffer halves alternate: a peer can be at most
+// one exchange ahead (its next push needs this rank's push of the exchange in between).
+constexpr int XCHG_MAX_RANKS = 64;
+struct XchgParams {
+    const uint8_t *send;              // this rank's [DeltaHdr | cap DeltaRec]
+    uint8_t *peer[XCHG_MAX_RANKS];    // receive areas of all ranks as mapped HERE (peer[rank] = the local one)
+    unsigned long long flags_off;     // byte offset of the flag words inside a receive area: flags[2][n_ranks] u64
+    unsigned long long half_bytes;    // bytes of one buffer half (n_ranks * stride)
+    unsigned long long stride;        // bytes of one rank's slot
+    unsigned long long seq;           // this exchange's number (>= 1)
+    uint32_t rank, n_ranks, cap;
+    unsigned long long timeout_ticks; // 100 MHz ticks the wait may take before the job is stopped (a peer died)
+    DevState *st;
+};
+__global__ __launch_bounds__(BLOCK) void k_xchg_push(XchgParams P) {
+    const uint32_t p = blockIdx.x; // destination rank
+    if (p >= P.n_ranks) return;
+    const DeltaHdr *h = reinterpret_cast<const DeltaHdr *>(P.send);
+    const unsigned long long n = min(h->count, (unsigned long long)P.cap);
+    const unsigned long long words = 2ull + 2ull * n; // u64 words: header + records
+    const unsigned long long half = (P.seq & 1ull) * P.half_bytes;
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(P.peer[p] + half + (unsigned long long)P.rank * P.stride);
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(P.send);
+    for (unsigned long long i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    __threadfence_system(); // (every thread: its stores are written back before the flag can be seen)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *flag = reinterpret_cast<unsigned long long *>(P.peer[p] + P.flags_off) + (P.seq & 1ull) * P.n_ranks + P.rank;
+        __hip_atomic_store(flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (p != P.rank) return;
+    // the local workgroup: wait for every peer's flag of this exchange (they land in this rank's memory)
+    if (threadIdx.x < P.n_ranks) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(P.peer[P.rank] + P.flags_off) + (P.seq & 1ull) * P.n_ranks + threadIdx.x;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(const_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < P.seq) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > P.timeout_ticks) { // a peer is gone: stop the job instead of hanging the device
+                atomicMax(&P.st->halt_req, (uint32_t)HALT_COMM);
+                break;
+            }
+        }
+    }
 }
 
 // out[i] = sum over rows r of in[r * n + i]

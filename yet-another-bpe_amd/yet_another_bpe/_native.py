@@ -42,7 +42,7 @@ class Stats(ctypes.Structure):
             "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans", "fused_launches")] + [
         ("dense_ms_sampled", c_double)] + [(n, c_uint64) for n in ("dense_launches_sampled", "dense_algo_bytes_sampled", "dense_actual_bytes_sampled")] + [
         ("sparse_ms", c_double), ("sparse_merges", c_uint64), ("tail_ms", c_double), ("tail_merges", c_uint64)] + [
-        (n, c_uint64) for n in ("exchanges", "exchange_bytes", "exchange_cap_records", "exchange_growths", "exchange_max_records", "sparse_launches", "tail_launches")]
+        (n, c_uint64) for n in ("exchanges", "exchange_bytes", "exchange_cap_records", "exchange_growths", "exchange_max_records", "sparse_launches", "tail_launches")] + [("exchange_ms_sampled", c_double), ("exchanges_sampled", c_uint64), ("exchange_p2p", c_uint64)]
 
 
 class Latency(ctypes.Structure):
@@ -59,7 +59,7 @@ SYMBOLS = [
     "yabpe_set_vocab", "yabpe_load_words", "yabpe_train", "yabpe_n_tokens", "yabpe_token_bytes", "yabpe_stats",
     "yabpe_iter_log", "yabpe_event_log", "yabpe_latency_probe", "yabpe_verify_table", "yabpe_stream_checksum", "yabpe_synth_generate", "yabpe_synth_generate_lex", "yabpe_synth_free",
     "yabpe_memcpy_d2h", "yabpe_memcpy_h2d", "yabpe_pretokenize", "yabpe_pretokenize_free",
-    "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom",
+    "yabpe_comm_unique_id", "yabpe_comm_init", "yabpe_comm_init_custom", "yabpe_comm_enable_p2p",
 ]
 
 
@@ -102,6 +102,7 @@ def lib() -> ctypes.CDLL:
         L.yabpe_comm_unique_id.argtypes = [c_void_p]
         L.yabpe_comm_init.argtypes = [c_void_p, c_int, c_int, c_void_p]
         L.yabpe_comm_init_custom.argtypes = [c_void_p, c_int, c_int, ALLGATHER_FN, c_void_p]
+        L.yabpe_comm_enable_p2p.argtypes = [c_void_p]
         if L.yabpe_abi_version() != 2:
             raise ImportError("libyabpe.so ABI version mismatch")
         _lib = L
@@ -317,6 +318,10 @@ class Context:
                 return -1
         self._ag_cb = ALLGATHER_FN(_cb)  # keep alive
         self._chk(lib().yabpe_comm_init_custom(self._h, rank, n_ranks, self._ag_cb, None))
+
+    def comm_enable_p2p(self) -> None:
+        """Peer-to-peer exchange (hipIpc-mapped receive buffers) instead of the all-gather; collective."""
+        self._chk(lib().yabpe_comm_enable_p2p(self._h))
 
     def d2h(self, dev_ptr: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
         out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)

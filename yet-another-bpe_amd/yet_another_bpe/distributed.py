@@ -8,6 +8,8 @@ stand-in transport.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import Callable, Sequence
 
@@ -87,9 +89,19 @@ def host_memory_transport(group=None) -> TorchTransport:
 
 
 def attach(ctx, rank: int, world: int, transport: str = "rccl") -> None:
-    """Attach a communicator to a _native.Context (before load_words).  transport: "rccl" | "torch"."""
+    """Attach a communicator to a _native.Context (before load_words).  transport: "rccl" | "torch", with "+p2p" appended (or
+    YABPE_P2P=1): the per-batch exchange then goes peer to peer through hipIpc-mapped buffers (yabpe_comm_enable_p2p) and the
+    named transport only carries the handles and the rare small agreements."""
     if world == 1:
         return
+    p2p = transport.endswith("+p2p") or os.environ.get("YABPE_P2P") == "1"
+    transport = transport[:-4] if transport.endswith("+p2p") else transport
+    _attach_transport(ctx, rank, world, transport)
+    if p2p:
+        ctx.comm_enable_p2p()
+
+
+def _attach_transport(ctx, rank: int, world: int, transport: str) -> None:
     import torch
     import torch.distributed as dist
 
