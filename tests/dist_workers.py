@@ -267,7 +267,9 @@ def gpu_device_text_sharded(rank, world, dist, meta_name, n_merges=None):
 
     cfg = BBPETrainerConfig(vocab_size=257 + (n_merges or meta["n_merges"]), min_frequency=meta["min_frequency"], special_tokens=meta["special_tokens"],
                             chunk_size_bytes=meta["chunk_size_bytes"])
-    left, right, merged, count, st, n_pre = train_device_text_sharded(lambda: _native.Context(0), make_text, cfg, rank, world, transport="torch")
+    # (the exchanges go peer to peer: through host memory -- gloo -- the 50,000-merge job spends a minute in the transport alone)
+    left, right, merged, count, st, n_pre = train_device_text_sharded(lambda: _native.Context(0), make_text, cfg, rank, world, transport="torch+p2p")
+    assert st["exchange_p2p"] == 1
     h = hashlib.sha256(left.astype(np.uint32).tobytes() + right.astype(np.uint32).tobytes() + merged.astype(np.uint32).tobytes()).hexdigest()
     # the byte-level merges list as the golden files serialise it (for a prefix of the job only the prefix digests apply)
     toks = [bytes([b]) for b in range(256)] + [t.encode() for t in meta["special_tokens"]]

@@ -127,15 +127,14 @@ def test_config5_text_utf8_long_tokens(golden_dir, meta_name):
 
 @pytest.mark.parametrize("meta_name", G10)
 def test_config5_text_two_ranks(golden_dir, meta_name):
-    """The same job over two ranks (sharing the test box's GPU, custom transport): each pre-tokenises and pools its chunks."""
+    """The same job over two ranks (sharing the test box's GPU; records exchanged peer to peer): each pre-tokenises and pools its chunks."""
     from tests import dist_workers
 
     path = golden_dir / meta_name
     if not path.exists():
         pytest.skip(f"{meta_name} has not been generated")
     meta = json.loads(path.read_text())
-    # (the 8 GiB job: its first 10,000 merges -- every exchange of this transport goes through host memory)
-    n_merges = 10000 if meta["text_bytes"] > (1 << 30) else meta["n_merges"]
+    n_merges = meta["n_merges"]
     outs = dist_workers.spawn(dist_workers.gpu_device_text_sharded, 2, meta_name, n_merges, timeout=1500)
     for digest, got, n_pre, n_words, n_long, merges_digest in outs:
         assert got == n_merges and merges_digest == meta["merges_sha256"][str(n_merges)]

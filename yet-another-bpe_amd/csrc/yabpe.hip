@@ -1187,8 +1187,10 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
             return fail(c, YABPE_E_HIP, "long-word scan failed: %s", hipGetErrorString(hipGetLastError()));
         }
         unsigned long long long_total = 0, too_long = 0;
-        HIPCHK(c, hipMemcpy(&long_total, c->long_off + c->n_long, 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&too_long, &c->scratch64[2], 8, hipMemcpyDeviceToHost));
+        // (on the context's stream: it does not synchronise with the null stream, and a one-block scan returns without waiting)
+        HIPCHK(c, hipMemcpyAsync(&long_total, c->long_off + c->n_long, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&too_long, &c->scratch64[2], 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         dfree(d_ll);
         if (too_long & 0xFFFFFFFFull) { cleanup_inputs(); return fail(c, YABPE_E_CAPACITY, "a single word longer than 2^32-1 bytes"); }
         TRY(dmalloc(c, &c->long_tok, long_total));
