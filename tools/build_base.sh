@@ -10,6 +10,9 @@ for f in yabpe.hip yabpe_kernels.h yabpe_aux_kernels.h yabpe_pretok_kernels.h pr
   git -C "$ROOT" show "$REV:yet-another-bpe_amd/csrc/$f" > $T/pkg/csrc/$f
 done
 git -C "$ROOT" show "$REV:include/yabpe.h" > $T/include/yabpe.h
-(cd $T/pkg/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -shared -o "$ROOT/yet-another-bpe_amd/csrc/libyabpe_base.so" yabpe.hip)
+# (the flags of THAT revision's Makefile: an A/B run must not credit a build flag to the change under test)
+git -C "$ROOT" show "$REV:yet-another-bpe_amd/csrc/Makefile" > $T/pkg/csrc/Makefile
+FLAGS=$(sed -n 's/^CXXFLAGS ?= //p' $T/pkg/csrc/Makefile)
+(cd $T/pkg/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -shared -o "$ROOT/yet-another-bpe_amd/csrc/libyabpe_base.so" yabpe.hip)
 rm -rf $T
 echo "built libyabpe_base.so from $REV"

@@ -1931,9 +1931,17 @@ int yabpe_stats(yabpe_ctx *c, yabpe_stats_t *out) {
 int yabpe_latency_probe(yabpe_ctx *c, yabpe_latency_t *out) {
     if (!c || !out) return YABPE_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t n = 1u << 29;  // 2 GiB of u32: eight times the Infinity Cache, so a hop finds its line in no cache
+    // 2 GiB of u32 (eight times the Infinity Cache: a hop finds its line in no cache); 512 MiB when the device is nearly full
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint32_t n = free_b > (8ull << 30) ? (1u << 29) : (1u << 27);
     uint32_t *next = nullptr, *sink = nullptr;
     unsigned long long *ticks = nullptr;
+    struct Guard {  // (every way out frees the probe's buffers)
+        uint32_t *&a, *&b;
+        unsigned long long *&t;
+        ~Guard() { dfree(a); dfree(b); dfree(t); }
+    } guard{next, sink, ticks};
     TRY(dmalloc(c, &next, n));
     TRY(dmalloc(c, &sink, 1));
     TRY(dmalloc(c, &ticks, 1));
@@ -1941,7 +1949,7 @@ int yabpe_latency_probe(yabpe_ctx *c, yabpe_latency_t *out) {
     const uint32_t hops = 1024;
     for (int mode = 0; mode < 3; ++mode) {
         // (the table is rewritten before every walk: whatever the last walk left in the caches is pushed out, and each walk is timed once, cold)
-        hipLaunchKernelGGL(k_chain_init, dim3(n / 256), dim3(256), 0, c->stream, next, n, 40503u * 4096u + 4099u + 2u * (uint32_t)mode);  // (odd: one cycle; far strides)
+        hipLaunchKernelGGL(k_chain_init, dim3(n / 256), dim3(256), 0, c->stream, next, n, (uint32_t)mode);  // (one cycle over all entries, no fixed stride)
         hipLaunchKernelGGL(k_chain_walk, dim3(1), dim3(1), 0, c->stream, next, hops, mode, ticks, sink);
         HIPCHK(c, hipGetLastError());
         unsigned long long t = 0;
@@ -1967,7 +1975,6 @@ int yabpe_latency_probe(yabpe_ctx *c, yabpe_latency_t *out) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    dfree(next); dfree(sink); dfree(ticks);
     out->launch_gap_us = gap;
     out->load_trip_us = trip[0];
     out->coherent_trip_us = trip[1];

@@ -515,12 +515,16 @@ __global__ __launch_bounds__(BLOCK) void k_retile(RetileParams P) {
 
 // ================================================================ latency probe (measurement; include/yabpe.h yabpe_latency_probe)
 // The pieces the per-merge launch is built from, measured on an otherwise idle device: one lane walks a chain of dependent
-// accesses through a table far larger than the caches (a random cyclic permutation), so every hop is a full trip to memory.
+// accesses through a table far larger than the caches, so every hop is a full trip to memory.  The chain is the full-period
+// affine map x -> (a x + c) mod 2^k (a = 1 mod 4, c odd: one cycle over all entries): consecutive hops land on unrelated
+// lines AND unrelated pages, like the scattered accesses of the launch (a constant stride -- what this probe used until
+// round 3 -- makes every hop a TLB miss of the same kind and overstates the trip by that much).
 //   mode 0: plain loads   mode 1: device-scope loads (past the caches; what hand-offs inside a launch use)
 //   mode 2: returning device-scope atomic adds (the adds of the aggregator flush whose results the selection needs)
-__global__ void k_chain_init(uint32_t *next, uint32_t n, uint32_t stride) { // next[i] = (i + stride) mod n: one cycle when gcd = 1
+__global__ void k_chain_init(uint32_t *next, uint32_t n, uint32_t salt) { // n a power of two; next[i] = (a i + c) mod n
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) next[i] = (uint32_t)(((unsigned long long)i + stride) % n);
+    const uint32_t a = 1664525u, c = 1013904223u + 2u * salt; // (a = 1 mod 4, c odd)
+    if (i < n) next[i] = (a * i + c) & (n - 1u);
 }
 __global__ void k_chain_walk(uint32_t *next, uint32_t hops, int mode, unsigned long long *out_ticks, uint32_t *sink) {
     uint32_t x = 0;

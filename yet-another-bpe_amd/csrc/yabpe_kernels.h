@@ -285,7 +285,6 @@ __device__ __forceinline__ void gt_add_from(const PairTable &t, DevState *st, ui
         }
         s = pt_next(t, s);
     }
-    // (a per-rank delta table that runs out of probes is grown together with the exchange buffers, not the replica)
     atomicMax(&st->halt_req, (uint32_t)(t.entries == &st->delta_entries ? HALT_DELTA_FULL : HALT_TABLE_FULL));
 }
 __device__ __forceinline__ void gt_add(const PairTable &t, DevState *st, uint32_t key, long long d, uint32_t *inserted = nullptr) {
@@ -692,7 +691,7 @@ struct ApplyParams {
     const uint32_t *tile_wbase;
     const uint32_t *wfreq;
     uint32_t n_tiles;
-    PairTable out; // where deltas go: the pair table (1 GPU) or the per-rank delta table (multi-GPU)
+    PairTable out; // where deltas go: the pair table (1 GPU) or this rank's send buffer as records (multi-GPU: PairTable::sink_*)
     DevState *st;
     unsigned long long *blk_stats; // [2 * gridDim.x]: sites merged, slots freed per workgroup (plain stores)
     unsigned long long *sig;       // tile signatures (may be NULL)
@@ -3146,11 +3145,12 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(RehashParams P) {
 }
 
 // ================================================================ multi-GPU: exchange of aggregated pair-count deltas
-// Every rank owns a shard of the words and a replica of the pair table.  Its apply pass adds into a small per-rank
-// delta table; k_delta_extract turns that into [header | records], one RCCL all-gather moves all ranks' buffers,
-// k_delta_apply adds every rank's records into the replica.  Integer sums are order-independent, so all replicas
-// hold identical counts and every rank selects the same merge.  A rank that must stop (overflow) says so in its
-// header: all ranks then stop at the same iteration.
+// Every rank owns a shard of the words and a replica of the pair table.  Its apply pass leaves its pair-count updates as
+// [header | (key, delta) records] in its send buffer (the aggregator flush writes them there: flush_entries' record sink);
+// the exchange -- k_xchg_push peer to peer, or one all-gather -- brings every rank's buffer to every rank, and k_delta_apply
+// adds all of them into the replica.  Integer sums are order-independent, so all replicas hold identical counts and every
+// rank selects the same batch of merges.  A rank that must stop (overflow) says so in its header: all ranks then stop at
+// the same iteration.
 
 struct DeltaApplyParams {
     const uint8_t *recv; // n_ranks buffers of stride bytes: DeltaHdr, then cap DeltaRec
