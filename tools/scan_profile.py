@@ -5,7 +5,7 @@ rewrites done, 4 loop left, 7 end (after the aggregator flush).  Prints the spre
 import ctypes, os, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
-os.environ["YABPE_LIB"] = str(REPO / "yet-another-bpe_amd/csrc/libyabpe_scanprof.so")
+os.environ["YABPE_LIB"] = os.environ.get("SCANPROF_LIB", str(REPO / "yet-another-bpe_amd/csrc/libyabpe_scanprof.so"))
 sys.path.insert(0, str(REPO / "yet-another-bpe_amd"))
 import numpy as np
 from yet_another_bpe import _native, synth
@@ -70,7 +70,10 @@ with _native.Context() as g:
                 m_ = (ne >= lo) & (ne < hi)
                 if m_.any():
                     print(f"    WGs with {lo:3d}..{hi if hi < 10**9 else 'inf'} entries: n {m_.sum():5d}  keys {us(f[m_,1]-f[m_,0]).mean():6.2f}  adds {us(f[m_,2]-f[m_,1]).mean():6.2f} (max {us(f[m_,2]-f[m_,1]).max():6.2f})  cand phase {us(scan[m_,2]-scan[m_,1]).mean():6.2f} us")
-            ss = (ctypes.c_uint64 * 8)(); _native.lib().yabpe_debug_ss_profile(ss); ss = list(ss)
+            ss = (ctypes.c_uint64 * 16)(); _native.lib().yabpe_debug_ss_profile(ss); ss = list(ss)
+            if ss[9]:
+                print("  candidate loop (workgroup 7, cumulative over the run): %d tiles, %.0f cycles per tile in the match+rewrite, %.1f %% rewritten in registers, %.1f %% by the general rewrite, %.1f %% without a site; %d groups, %.0f cycles waiting per group"
+                      % (ss[9], ss[8] / ss[9], 100.0 * ss[10] / ss[9], 100.0 * ss[11] / ss[9], 100.0 * ss[12] / ss[9], ss[14], ss[13] / max(1, ss[14])))
             if ss[0]:
                 print("  single_site_tile cycles/tile (workgroup 7, cumulative over the run): neighbours %.0f, deltas->LDS %.0f, sig bits %.0f, compaction+stores %.0f  (n=%d)"
                       % (ss[1] / ss[0], ss[2] / ss[0], ss[3] / ss[0], ss[4] / ss[0], ss[0]))
