@@ -1543,7 +1543,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     TRY(ensure_records(rec_first));
     HIPCHK(c, hipMemsetAsync(c->rec_sites, 0, (size_t)c->rec_cap * 8, c->stream));
 
-    const uint32_t check = (uint32_t)std::max<int64_t>(1, optv(c, "check_interval", 64));
+    const uint32_t check = (uint32_t)std::max<int64_t>(1, optv(c, "check_interval", 32));
     const uint32_t ev_sample = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample", 0));
     const uint32_t ev_sample_dense = (uint32_t)std::max<int64_t>(0, optv(c, "event_sample_dense", (int64_t)ev_sample));  // fused k_apply launches
     const double retile_frac = (double)optv(c, "retile_pct", 60) / 100.0;
@@ -2068,6 +2068,9 @@ int yabpe_memcpy_d2h(yabpe_ctx *c, void *dst_host, const void *src_dev, uint64_t
 #ifdef YB_PROFILE_SCAN
 int yabpe_debug_sel_profile(unsigned long long out[16]) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_sel_prof), 128) == hipSuccess ? 0 : -1;
+}
+int yabpe_debug_sel_acc(unsigned long long out[72]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_sel_acc), 72 * 8) == hipSuccess ? 0 : -1;
 }
 int yabpe_debug_ss_profile(unsigned long long out[8]) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(yb::g_ss_prof), 64) == hipSuccess ? 0 : -1;

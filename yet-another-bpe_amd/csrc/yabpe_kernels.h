@@ -1764,6 +1764,7 @@ __device__ unsigned long long g_stop_hist[65536]; // per selection (index: DevSt
 #define YB_STOP(it, why, n, nw) do { if (lane == 0) g_stop_hist[(it) & 0xFFFFu] = (unsigned long long)(why) | ((unsigned long long)(n) << 8) | ((unsigned long long)(nw) << 16); } while (0)
 __device__ unsigned long long g_launch_prof[65536 * 4]; // per merge: min start, max end of the workgroups, -, selection end
 __device__ unsigned long long g_sel_prof[16];
+__device__ unsigned long long g_sel_acc[3 * 24]; // three ranges of merges x (count, sum of stamp i - stamp 8 ..., [12] merges selected, [13] window entries)
 #define YB_SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_prof[i] = wall_clock64(); } while (0)
 #else
 #define YB_SEL_STAMP(i) do { } while (0)
@@ -2101,9 +2102,15 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
 __device__ __forceinline__ void select_eval(const SelectParams &P) {
     __shared__ WinEnt s_win[WIN];
     __shared__ AccEnt s_acc[KMAX];
-    __shared__ uint32_t s_hset[2 * WIN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hset[2 * WIN]; // (the window's hash set; afterwards the packed sort keys live here)
     __shared__ unsigned long long s_red[WPB], s_fold[2];
     __shared__ uint32_t s_nwin;
+    struct TopEnt { unsigned long long cnt; uint32_t key, win; }; // the entry at a position of the selection order
+    __shared__ unsigned long long s_lim[2];
+    __shared__ uint32_t s_flags[2];
+    unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_hset); // [WIN]
+    __shared__ TopEnt s_top[KMAX];
+    static_assert(BLOCK == 2 * WIN, "two threads rank one window entry");
     constexpr uint32_t HSET = 2 * WIN;
     DevState *st = P.st;
     const int tid = threadIdx.x;
@@ -2138,6 +2145,10 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         s_fold[0] = 0;
         s_fold[1] = 0;
         s_nwin = 0;
+        s_flags[0] = 0u; // positions of the selection order that fail the batch rule
+        s_flags[1] = 0u; // positions that hold a run merge (p == q)
+        s_lim[0] = candT;
+        s_lim[1] = d_min_freq;
     }
     unsigned long long vx[4], vy[4];
 #pragma unroll
@@ -2203,6 +2214,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < WPB; ++w) cmax = s_red[w] > cmax ? s_red[w] : cmax;
+    YB_SEL_STAMP(12);
     // ---- the window: the DISTINCT pairs with count >= L = cmax - delta (whole count levels by construction; a pair may be
     // listed more than once, and how often differs between the replicas of a multi-GPU job: the set keeps repeats out, so every
     // rank walks the same window).  More than WIN of them: a quarter of the distance, again.
@@ -2210,7 +2222,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     uint32_t n_win = 0;
     uint32_t wshift = min(max(st->win_shift, 2u), 20u), narrowed = 0;
     if (cmax) {
-        unsigned long long delta = kmax > 1u ? max((unsigned long long)kmax, cmax >> wshift) : 0ull;
+        unsigned long long delta = kmax > 1u ? min(max((unsigned long long)kmax, cmax >> wshift), 1ull << 31) : 0ull;
         for (int attempt = 0; attempt < 8; ++attempt) {
             L = cmax > delta ? cmax - delta : 1ull;
             auto put = [&](unsigned long long ent, unsigned long long c) {
@@ -2286,6 +2298,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         __syncthreads();
         n_win = 1;
     }
+    YB_SEL_STAMP(13);
     // ---- round trip 3: the two token records of every window entry (one entry per thread)
     if ((uint32_t)tid < n_win) {
         const uint32_t key = s_win[tid].key;
@@ -2300,51 +2313,92 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         s_win[tid].hy = hy;
         s_win[tid].px = px;
         s_win[tid].py = py;
+        // (the sort key: count above the window's floor, then the lexranks -- count - L < 2^32: delta is capped)
+        s_pk[tid] = ((s_win[tid].cnt - L) << 32) | (unsigned long long)(((uint32_t)ax << 16) | ((uint32_t)ay & 0xffffu));
+    } else if (tid < WIN) {
+        s_pk[tid] = 0ull; // (never above anything)
     }
     __syncthreads();
     YB_SEL_STAMP(11);
-    if (tid >= 64) return; // ---- from here on: wave 0 alone, wave-level synchronisation only
-    // A lane keeps two window entries in registers: count, key, lexranks, and two bit sets over the merges accepted so far --
-    // ra: bit i = "my right token is a_i", lb: bit i = "my left token is b_i" (what rules (1) and (2) ask about).
-    unsigned long long mc[2] = {0ull, 0ull};
-    uint32_t mkey[2] = {0u, 0u}, mrk[2] = {0u, 0u}, mra[2] = {0u, 0u}, mlb[2] = {0u, 0u};
-    bool mlive[2] = {false, false}; // in the window and not walked yet
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t idx = (uint32_t)lane + 64u * h;
-        if (idx < n_win) {
-            mc[h] = s_win[idx].cnt;
-            mkey[h] = s_win[idx].key;
-            mrk[h] = s_win[idx].rk;
-            mlive[h] = true;
+    // ---- the batch rule (above select_body), for every window entry side by side instead of a walk.  The entries in
+    // selection order are the window sorted by (count, lexranks) descending -- distinct pairs: no ties -- and the merges
+    // accepted before position j are exactly positions 0 .. j-1, so everything rule (1) and rule (2) ask about position j is
+    // known without walking: an entry's two bit sets over the first KMAX positions (ra: bit i = "my right token is a_i",
+    // lb: bit i = "my left token is b_i"), cut to the bits below j.  The batch is the prefix in front of the first position
+    // that fails.  Position by counting: every entry against every other, packed keys in LDS (written with the records
+    // above; two lanes of one wave per entry, 32 keys each, two keys per LDS read).
+    const uint32_t wt = (uint32_t)(tid >> 6) * 32u + ((uint32_t)lane & 31u), whalf = (uint32_t)lane >> 5; // (BLOCK == 2 * WIN)
+    uint32_t my_pos = 0xffffu, my_key = 0u;
+    unsigned long long my_cnt = 0ull;
+    {
+        const unsigned long long mine = s_pk[wt];
+        const ulonglong2 *pk2 = reinterpret_cast<const ulonglong2 *>(s_pk) + whalf * (uint32_t)(WIN / 4);
+        uint32_t above = 0;
+#pragma unroll 8
+        for (uint32_t m = 0; m < (uint32_t)(WIN / 4); ++m) {
+            const ulonglong2 kk = pk2[m];
+            above += (kk.x > mine ? 1u : 0u) + (kk.y > mine ? 1u : 0u);
         }
-    }
-    // the next entry in selection order: the maximum by (count, lexranks) of what has not been walked (distinct pairs: no ties)
-    struct Cand { unsigned long long cnt; uint32_t rk, key, win, ralb; };
-    auto next_cand = [&]() -> Cand {
-        Best loc{0ull, 0u, EMPTY, 0u, 0u};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const Best b{mlive[h] ? mc[h] : 0ull, mrk[h], mkey[h], (uint32_t)lane + 64u * h, 0u};
-            if (mlive[h] && best_gt(b, loc)) loc = b;
-        }
-        const Best w = best_wave_reduce(loc); // (.slot carries the window index)
-        uint32_t ralb = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool me = w.cnt != 0ull && w.slot == (uint32_t)lane + 64u * h;
-            if (me) {
-                mlive[h] = false;
-                ralb = mra[h] | mlb[h];
+        above += __shfl_xor(above, 32);
+        if (whalf == 0u && wt < n_win) {
+            my_pos = above;
+            my_key = s_win[wt].key;
+            my_cnt = s_win[wt].cnt;
+            if (my_pos < (uint32_t)KMAX) {
+                s_top[my_pos] = TopEnt{my_cnt, my_key, wt};
+                s_acc[my_pos] = AccEnt{my_key >> 16, my_key & 0xffffu, s_win[wt].lx + s_win[wt].ly, wt, pre8_concat(s_win[wt].px, s_win[wt].lx, s_win[wt].py)};
             }
         }
-        const unsigned long long own = __ballot(ralb != 0u);
-        return Cand{w.cnt, w.rk, w.key, w.slot, own ? 1u : 0u};
-    };
+    }
+    __syncthreads();
+    const uint32_t n_top = min(n_win, (uint32_t)KMAX);
+    if (my_pos != 0xffffu) {
+        const uint32_t topmask = (1u << n_top) - 1u;
+        uint32_t ra = 0, lb = 0, tie = 0;
+#pragma unroll
+        for (uint32_t i2 = 0; i2 < (uint32_t)KMAX; ++i2) { // (positions >= n_top hold stale entries: masked below)
+            const TopEnt te = s_top[i2];
+            ra |= (uint32_t)((my_key & 0xffffu) == (te.key >> 16)) << i2;
+            lb |= (uint32_t)((my_key >> 16) == (te.key & 0xffffu)) << i2;
+            tie |= (uint32_t)(te.cnt == my_cnt) << i2;
+        }
+        ra &= topmask;
+        lb &= topmask;
+        if (my_pos < (uint32_t)KMAX) {
+            const uint32_t below = (1u << my_pos) - 1u;
+            // rule (1): q is some a_i or p some b_i of an earlier position; and the stop rules for a position behind the first
+            if (my_pos != 0u && (((ra | lb) & below) != 0u || my_cnt < s_lim[0] || my_cnt < s_lim[1])) atomicOr(&s_flags[0], 1u << my_pos);
+            if ((my_key >> 16) == (my_key & 0xffffu)) atomicOr(&s_flags[1], 1u << my_pos); // rule (3): a run merge closes the batch
+        }
+        // rule (2): I tie with position j, come after it, and hold a token a merge in front of j consumes: may I turn into a
+        // pair that sorts in front of j?  Positions that qualify: tying, behind the first merge that touches one of my tokens,
+        // in front of me.  (rare: only then are the records read)
+        const uint32_t touch = ra | lb;
+        uint32_t cand = touch ? tie & topmask & ~((2u << (__ffs((int)touch) - 1)) - 1u) & (my_pos < (uint32_t)KMAX ? (1u << my_pos) - 1u : ~0u) : 0u;
+        for (; cand; cand &= cand - 1u) {
+            const uint32_t j2 = (uint32_t)__ffs((int)cand) - 1u, below = (1u << j2) - 1u;
+            const uint32_t cwin = s_top[j2].win;
+            const unsigned long long c_px = s_win[cwin].px, c_py = s_win[cwin].py;
+            const uint32_t c_lx = s_win[cwin].lx, c_ly = s_win[cwin].ly;
+            bool left_new_blocks = false, right_new_ge = false;
+            for (uint32_t m = lb & below; m; m &= m - 1u) { // (c_i, .) against (p, .)
+                const AccEnt A = s_acc[__ffs((int)m) - 1];
+                left_new_blocks |= cmp_pre8(A.pc, A.lc, c_px, c_lx) != -1;
+            }
+            for (uint32_t m = ra & below; m; m &= m - 1u) { // (., c_i) against (., q)
+                const AccEnt A = s_acc[__ffs((int)m) - 1];
+                right_new_ge |= cmp_pre8(A.pc, A.lc, c_py, c_ly) != -1;
+            }
+            const uint32_t rl = s_win[wt].rk >> 16, rp = s_win[cwin].rk >> 16; // lexranks of my left token and of p
+            if (left_new_blocks || ((ra & below) != 0u && (rl > rp || (rl == rp && right_new_ge)))) atomicOr(&s_flags[0], 1u << j2);
+        }
+    }
+    __syncthreads();
+    YB_SEL_STAMP(14);
+    if (tid >= 64) return; // ---- from here on: wave 0 alone, wave-level synchronisation only
     // ---- stop rules and the first merge (lane 0 holds the state)
     uint32_t flag = 0; // 1: nothing selected (done / halt)
-    Cand cj = next_cand();
-    const unsigned long long best_cnt = cj.cnt;
+    const unsigned long long best_cnt = cmax;
     if (lane == 0) {
         if (d_halt == 0 && d_halt_req != 0) d_halt = d_halt_req;
         if (P.delta_hdr) { // this rank's send header for the next exchange
@@ -2387,69 +2441,20 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     flag = __builtin_amdgcn_readfirstlane(flag);
     if (flag) return;
     YB_SEL_STAMP(3);
-    // ---- the walk (the batch rule above select_body): the window's entries in selection order
+    // ---- the batch: positions [0, nacc) -- up to the first position that fails, the first run merge included, the limits
     const uint32_t it0 = __builtin_amdgcn_readfirstlane(d_iter), num_merges = __builtin_amdgcn_readfirstlane(d_num_merges);
-    const unsigned long long T_all = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(candT >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)candT);
-    const unsigned long long minf = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(d_min_freq >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)d_min_freq);
-    uint32_t nacc = 0, why = 0;
+    uint32_t nacc = min(min(kmax, num_merges - it0), n_top), why = 4u;
     (void)why;
-    while (true) {
-        const uint32_t p = cj.key >> 16, q = cj.key & 0xffffu;
-        if (nacc) {
-            // rule (1): the candidate's own bit sets say whether q is some a_i or p some b_i
-            if (cj.cnt == 0ull || cj.cnt < T_all || cj.cnt < minf || cj.ralb) {
-                why = cj.ralb ? 1u : cj.cnt < T_all ? 3u : 5u;
-                break;
-            }
-            // rule (2): the pairs that tie with the candidate and come after it (not walked yet), with a token an accepted merge consumes
-            bool blocks = false;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (!mlive[h] || mc[h] != cj.cnt || (mra[h] | mlb[h]) == 0u) continue; // (rare from here on)
-                const uint32_t cwin = cj.win;
-                const unsigned long long c_px = s_win[cwin].px, c_py = s_win[cwin].py;
-                const uint32_t c_lx = s_win[cwin].lx, c_ly = s_win[cwin].ly;
-                bool left_new_blocks = false, right_new_ge = false;
-                for (uint32_t m = mlb[h]; m; m &= m - 1u) { // (c_i, .) against (p, .)
-                    const AccEnt A = s_acc[__ffs((int)m) - 1];
-                    left_new_blocks |= cmp_pre8(A.pc, A.lc, c_px, c_lx) != -1;
-                }
-                for (uint32_t m = mra[h]; m; m &= m - 1u) { // (., c_i) against (., q)
-                    const AccEnt A = s_acc[__ffs((int)m) - 1];
-                    right_new_ge |= cmp_pre8(A.pc, A.lc, c_py, c_ly) != -1;
-                }
-                const uint32_t rl = mrk[h] >> 16, rp = cj.rk >> 16; // lexranks of l and p
-                blocks |= left_new_blocks || (mra[h] != 0u && (rl > rp || (rl == rp && right_new_ge)));
-            }
-            if (__any(blocks)) {
-                why = 2u;
-                break;
-            }
+    {
+        const uint32_t fails = s_flags[0] & ~1u, runs = s_flags[1];
+        if (nacc == n_top && n_top < kmax && n_top < num_merges - it0) why = 5u; // the window is walked through
+        if (fails && (uint32_t)(__ffs((int)fails) - 1) < nacc) {
+            nacc = (uint32_t)(__ffs((int)fails) - 1);
+            why = 1u;
         }
-        // accept
-        if (lane == 0) {
-            const uint32_t cwin = cj.win;
-            s_acc[nacc] = AccEnt{p, q, s_win[cwin].lx + s_win[cwin].ly, cwin, pre8_concat(s_win[cwin].px, s_win[cwin].lx, s_win[cwin].py)};
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            mra[h] |= (uint32_t)((mkey[h] & 0xffffu) == p) << nacc;
-            mlb[h] |= (uint32_t)((mkey[h] >> 16) == q) << nacc;
-        }
-        wave_sync();
-        ++nacc;
-        if (p == q) { // rule (3): a run merge closes the batch
+        if (runs && (uint32_t)__ffs((int)runs) < nacc) {
+            nacc = (uint32_t)__ffs((int)runs);
             why = 6u;
-            break;
-        }
-        if (nacc >= kmax || it0 + nacc >= num_merges) {
-            why = 4u;
-            break;
-        }
-        cj = next_cand();
-        if (cj.cnt == 0ull) { // the window is walked through
-            why = 5u;
-            break;
         }
     }
     YB_STOP(it0, why, nacc, n_win);
@@ -2531,6 +2536,17 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         }
     }
     YB_SEL_STAMP(7);
+#ifdef YB_PROFILE_SCAN
+    if (threadIdx.x == 0 && kmax > 1u && keep != 0u) { // (batch selections only: where the time of a selection goes, by phase of the job)
+        unsigned long long *acc = g_sel_acc + (it0 < 3000u ? 0 : it0 < 12000u ? 24 : 48);
+        acc[0] += 1ull;
+        const int ids[10] = {1, 9, 10, 12, 13, 11, 14, 3, 5, 7};
+        for (int q = 0; q < 10; ++q) acc[ids[q]] += g_sel_prof[ids[q]] - g_sel_prof[8];
+        acc[16] += keep;
+        acc[17] += n_win;
+        acc[18] += g_sel_prof[8] - g_sel_prof[0];
+    }
+#endif
     if (keep != 0u) return;
     // ---- the first merge could not be created blindly: its bytes may be a token already (trainer.py:298-300: then it keeps
     // that id), or there is no id / no pool space left.  Settled here by the whole wave, one merge, the batch ends with it.
