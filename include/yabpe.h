@@ -140,6 +140,10 @@ typedef struct yabpe_stats_t {
     double exchange_ms_sampled;
     uint64_t exchanges_sampled;
     uint64_t exchange_p2p;     /* 1: the exchanges go peer to peer (0: through the attached transport's all-gather) */
+    /* the streaming phase: its launches and the merges they applied (a launch applies a batch of up to "batch_max_stream"
+       merges in one pass over the stream); dense_algo_bytes_sampled / dense_actual_bytes_sampled are the phase's totals
+       scaled to the event-timed launches */
+    uint64_t dense_launches, dense_merges;
 } yabpe_stats_t;
 int yabpe_stats(yabpe_ctx *ctx, yabpe_stats_t *out);
 /* Per-iteration log of the last yabpe_train call: sites merged M_i and live slots read by iteration i. */

@@ -23,6 +23,12 @@ def _init(rank: int, world: int, port: int):
 
 
 def _run(fn, rank, world, port, q, *args):
+    import faulthandler
+    import signal
+
+    faulthandler.register(signal.SIGUSR1, all_threads=True)  # (kill -USR1 <worker>: where is a stuck rank?)
+    if os.environ.get("YABPE_TEST_DUMP_AFTER"):  # (debugging a stuck rank: Python stacks of all threads after N seconds, repeated)
+        faulthandler.dump_traceback_later(float(os.environ["YABPE_TEST_DUMP_AFTER"]), repeat=True)
     try:
         dist = _init(rank, world, port)
         out = fn(rank, world, dist, *args)

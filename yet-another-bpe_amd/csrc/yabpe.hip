@@ -193,7 +193,8 @@ struct yabpe_ctx {
     bool p2p = false;
     uint8_t *p2p_area = nullptr;               // this rank's receive area: 2 halves of n_ranks slots + the flag words (plain hipMalloc: exported)
     std::vector<uint8_t *> p2p_peer;           // every rank's area as mapped here (own rank: p2p_area)
-    uint64_t p2p_half = 0, p2p_flags_off = 0, p2p_seq = 0;
+    uint64_t p2p_half = 0, p2p_flags_off = 0, p2p_seq = 0, p2p_stride = 0;  // p2p_stride: bytes of one sender's slot in an area
+    uint32_t p2p_cap = 0;                      // records a slot holds (fixed for the job: the areas are mapped once)
     hipEvent_t p2p_e0 = nullptr, p2p_e1 = nullptr;  // (statistics: every 64th exchange is timed)
     bool p2p_pending = false;                  // an event pair was recorded and not read yet
 };
@@ -455,7 +456,9 @@ int cand_rebuild(yabpe_ctx *c, unsigned long long best_count) {
         }
         break;
     }
-    if (h.n < target / 8) c->cand_margin = std::min(0.2, c->cand_margin * 2.0); // room to spare: rebuild less often next time
+    // room to spare: rebuild less often next time -- and a batch can reach further down (early in a job the best counts lie
+    // far apart: a selection can only batch pairs that are on the list)
+    if (h.n < target / 8) c->cand_margin = std::min((double)optv(c, "cand_margin_max_pct", 60) / 100.0, c->cand_margin * 2.0);
     c->use_cand = !h.overflow && h.n < CAND_CAP / 2;
     c->cand_n_at_build = h.n;
     if (c->use_cand) {
@@ -701,33 +704,45 @@ int table_grow(yabpe_ctx *c, uint64_t new_cap) {
     return fail(c, YABPE_E_CAPACITY, "pair table does not fit");
 }
 
-void p2p_close(yabpe_ctx *c) {
+#define YB_TRACE_C(c, ...) do { if (optv(c, "trace_host", 0)) { fprintf(stderr, "[yabpe r%d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+// The peer-to-peer receive areas are exported and mapped ONCE per job, at their final size, and never freed while the job
+// lives.  Taking them down and up again when the exchange buffers grow (unmap, free, allocate, export, map) does not survive
+// on this runtime: about one time in five hipIpcOpenMemHandle of the re-exported area failed on one rank and never returned
+// on the other (two processes, one MI355X, the 8 GiB job's second growth) -- whether the ranks map one at a time or together,
+// with or without a barrier between unmapping and freeing.  A first mapping has never failed.
+void p2p_close(yabpe_ctx *c) {  // (yabpe_destroy: no collective here -- a peer may be gone)
     for (size_t r = 0; r < c->p2p_peer.size(); ++r)
         if (c->p2p_peer[r] && (int)r != c->rank) (void)hipIpcCloseMemHandle(c->p2p_peer[r]);
     c->p2p_peer.clear();
-    if (c->p2p_area) (void)hipFree(c->p2p_area);
+    // the own area: a peer may still have it mapped -- left to the process's exit (the driver drops it with its last mapping)
+    if (c->p2p_area && c->n_ranks <= 1) (void)hipFree(c->p2p_area);
     c->p2p_area = nullptr;
 }
 
-// (Re)build the peer-to-peer receive areas for the current buffer geometry: allocate, exchange the IPC handles through the
-// attached transport (one all-gather of 64 bytes per rank), map the peers' areas.  Collective: every rank calls it at the same
-// point and runs the same sequence of collectives whatever fails locally; if ANY rank could not export or map a buffer, all
-// ranks drop the peer-to-peer path together and keep exchanging through the transport (c->p2p = false, no error).
+// Build the peer-to-peer receive areas: `p2p_cap` records per sender and half (option "p2p_cap_records", 4 Mi = 64 MiB per
+// slot: 1 GiB of a rank's 288 GB at 8 ranks), exchange the IPC handles through the attached transport (one all-gather of
+// 64 bytes per rank), map the peers' areas.  Collective: every rank calls it at the same point and runs the same sequence of
+// collectives whatever fails locally; if ANY rank could not export or map a buffer, all ranks drop the peer-to-peer path
+// together and keep exchanging through the transport (c->p2p = false, no error).
 int p2p_setup(yabpe_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    p2p_close(c);
+    if (c->p2p_area) return 0;  // (once)
     unsigned long long failed = 0;
     std::string why;
     if (c->n_ranks > XCHG_MAX_RANKS) { failed = 1; why = "too many ranks"; }
-    c->p2p_half = c->xstride * (uint64_t)c->n_ranks;
+    c->p2p_cap = (uint32_t)std::max<int64_t>((int64_t)c->xcap, std::min<int64_t>(optv(c, "p2p_cap_records", 4ll << 20), 1ll << 28));
+    c->p2p_stride = 16 + (uint64_t)c->p2p_cap * sizeof(DeltaRec);
+    c->p2p_half = c->p2p_stride * (uint64_t)c->n_ranks;
     c->p2p_flags_off = (2 * c->p2p_half + 255) & ~255ull;
     const uint64_t bytes = c->p2p_flags_off + 2ull * c->n_ranks * 8 + 256;
     hipIpcMemHandle_t mine;
     memset(&mine, 0, sizeof mine);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     if (!failed) {
+        YB_TRACE_C(c, "p2p setup: allocate %llu bytes", (unsigned long long)bytes);
         hipError_t e = hipMalloc((void **)&c->p2p_area, bytes);
-        if (e == hipSuccess) e = hipMemset(c->p2p_area, 0, bytes);
+        // (only the flag words have to start at zero: a slot is read up to the count its header announces)
+        if (e == hipSuccess) e = hipMemset(c->p2p_area + c->p2p_flags_off, 0, bytes - c->p2p_flags_off);
         if (e == hipSuccess) e = hipIpcGetMemHandle(&mine, c->p2p_area);
         if (e != hipSuccess) { failed = 1; why = std::string("export: ") + hipGetErrorString(e); (void)hipGetLastError(); }
     }
@@ -750,12 +765,12 @@ int p2p_setup(yabpe_ctx *c) {
         c->p2p_peer[r] = (uint8_t *)q;
     }
     c->p2p_seq = 0;
+    YB_TRACE_C(c, "p2p setup: mapped (failed %llu)", failed);
     // nobody pushes before every rank has mapped everything -- and everybody learns whether somebody could not
     unsigned long long any_failed = 0;
     TRY(comm_max(c, failed, &any_failed));
     if (any_failed) {
-        p2p_close(c);
-        c->p2p = false;
+        c->p2p = false;  // (what is mapped stays mapped until yabpe_destroy: nothing is taken down while peers may be in the runtime)
         if (failed && optv(c, "trace_exchange", 0)) fprintf(stderr, "[yabpe r%d] peer-to-peer exchange not available here (%s): exchanging through the transport\n", c->rank, why.c_str());
     }
     return 0;
@@ -774,7 +789,11 @@ int comm_buffers(yabpe_ctx *c, uint32_t cap) {
     TRY(dmalloc(c, &c->xrecv, c->xstride * c->n_ranks));
     HIPCHK(c, hipMemsetAsync(c->xsend, 0, c->xstride, c->stream));
     HIPCHK(c, hipMemsetAsync(c->xrecv, 0, c->xstride * c->n_ranks, c->stream));
-    if (c->p2p) TRY(p2p_setup(c));  // (the slots have a new size: new areas, new handles -- every rank is here together)
+    // (the peer-to-peer areas keep their size: a buffer beyond it -- the same on every rank -- goes through the transport from here on)
+    if (c->p2p && c->p2p_area && cap > c->p2p_cap) {
+        c->p2p = false;
+        if (optv(c, "trace_exchange", 0)) fprintf(stderr, "[yabpe r%d] exchange buffers of %u records exceed the peer-to-peer areas (%u): exchanging through the transport\n", c->rank, cap, c->p2p_cap);
+    }
     return 0;
 }
 
@@ -1237,6 +1256,8 @@ int yabpe_load_words(yabpe_ctx *c, const uint8_t *bytes, const uint64_t *word_of
     c->stats.apply_actual_bytes_sampled = 0;
     c->stats.dense_ms_sampled = 0;
     c->stats.dense_launches_sampled = 0;
+    c->stats.dense_launches = 0;
+    c->stats.dense_merges = 0;
     c->stats.dense_algo_bytes_sampled = 0;
     c->stats.dense_actual_bytes_sampled = 0;
     c->stats.sparse_ms = 0;
@@ -1350,12 +1371,15 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             const FuseParams F = fuse_params(apply_grid);
             const uint32_t rr_blocks = rank_rides ? rank_blocks : 0u;
             c->blk_used = std::max(c->blk_used, apply_grid);
+            // (direct-indexed delta store: one LDS block per merge of the batch -- DevState::kmax is what a selection may take)
+            const uint32_t hist_k = std::max(1u, c->kmax_now);
             if (c->weighted)
-                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
-            else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V)  // (every token id this launch can meet indexes the direct store)
-                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks, 0u);
+            else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V && hist_k <= HIST_K_MAX)  // (every token id this launch can meet indexes the direct store)
+                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), hist_k * 4u * HIST_V * sizeof(int), c->stream, P, apply_grid, R, F, LW,
+                                   apply_grid + rr_blocks, hist_k);
             else
-                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks, 0u);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
             // sparse form: skip index + rewrite of the tiles that pass, a batch of merges per launch.
@@ -1423,7 +1447,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             for (int r = 0; r < c->n_ranks; ++r) X.peer[r] = c->p2p_peer[r];
             X.flags_off = c->p2p_flags_off;
             X.half_bytes = c->p2p_half;
-            X.stride = c->xstride;
+            X.stride = c->p2p_stride;
             X.seq = ++c->p2p_seq;
             X.rank = (uint32_t)c->rank;
             X.n_ranks = (uint32_t)c->n_ranks;
@@ -1438,7 +1462,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
                 c->p2p_pending = true;  // (read at the end of this round of launches)
             }
             recv = c->p2p_area + (X.seq & 1ull) * c->p2p_half;
-            rstride = c->xstride;
+            rstride = c->p2p_stride;
         } else {
             TRY(comm_allgather(c, c->xsend, c->xrecv, xbytes));
         }
@@ -1557,11 +1581,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     uint32_t split_at = 0, tail_at = 0;
 
     uint32_t i = 0;  // merges selected so far in this call (read back from the device between batches of launches)
+    const bool trace_host = optv(c, "trace_host", 0) != 0;  // (debugging a stuck multi-GPU job: where is this rank's host?)
+#define YB_TRACE(...) do { if (trace_host) { fprintf(stderr, "[yabpe r%d] ", c->rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
     bool finished = false;
     bool skip_cand_once = false;
     bool first_round = true;
     unsigned long long prev_best = 0;
-    uint64_t launches_sparse = 0, launches_at_tail = 0;
+    uint64_t launches_sparse = 0, launches_at_tail = 0, launches_dense = 0;
+    uint32_t dense_applied = 0;  // merges the streaming launches applied (what was selected when the form changed, less the pending batch)
     uint32_t cand_n_all = 0;  // length of the candidate list at the last read (multi-GPU: of the longest replica's)
     bool sparse_global = false;  // the sparse form has been called for (by any rank)
     c->use_cand = false;
@@ -1592,6 +1619,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         if (c->split_mode && !split_marked) {  // (measurement: where the streaming phase ends and the sparse phase begins)
             split_marked = true;
             split_at = i;
+            dense_applied = i - std::min<uint32_t>(i, c->pending ? h->n_batch : 0u);
             HIPCHK(c, hipEventRecord(T.t_split, c->stream));
         }
         if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
@@ -1612,6 +1640,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // every rank must rebuild at the same merges or their thresholds T drift apart)
             const bool long_list = cand_n_all > std::max<uint32_t>(4u * BLOCK - 64u, (uint32_t)optv(c, "cand_target", 768));  // (one pass of the fused selection: 4 entries per thread)
             if (!c->use_cand || i - c->cand_built_at >= every || i < c->cand_built_at || near_T || long_list) {
+                YB_TRACE("cand_rebuild at %u", i);
                 TRY(cand_rebuild(c, h->best_count));
                 c->cand_built_at = i;
                 c->cand_best_at_build = h->best_count;
@@ -1625,13 +1654,15 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             const uint64_t merged_since = c->sig_tokens_at_build > h->tokens_now ? c->sig_tokens_at_build - h->tokens_now : 0;
             const bool stale = merged_since * 100 > c->sig_tokens_at_build * (uint64_t)optv(c, "sig_rebuild_pct", 20);
             if (!c->sig_valid || i - c->sig_built_at >= every || i < c->sig_built_at || stale) {
+                YB_TRACE("build_signatures at %u", i);
                 TRY(build_signatures(c));
                 c->sig_valid = true;
                 c->sig_built_at = i;
             }
         }
-        // merges one selection may take: a batch in the sparse form (the streaming form applies one merge per launch)
-        const uint32_t kmax = sparse_now ? (uint32_t)std::max<int64_t>(1, std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX))) : 1u;
+        // merges one selection may take: a batch in either form (the streaming form's direct-indexed delta store holds one LDS
+        // block per merge: two keep four workgroups per CU)
+        const uint32_t kmax = (uint32_t)std::max<int64_t>(1, sparse_now ? std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX)) : std::min<int64_t>(HIST_K_MAX, optv(c, "batch_max_stream", 2)));
         if (kmax != c->kmax_now) {
             HIPCHK(c, hipMemcpyAsync(&c->st->kmax, &kmax, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             c->kmax_now = kmax;
@@ -1677,7 +1708,8 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 // multi-GPU form the send buffer would still hold the records of the first time.)
                 const bool last = i >= num_merges;
                 TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i - 1), true));
-                if (kmax == 1) ++i; else ++launches_sparse;
+                if (kmax == 1) ++i; else if (sparse_now) ++launches_sparse;  // (a batch per launch: i stays a lower bound until the next read)
+                if (!sparse_now) ++launches_dense;
                 if (last) break;
             } else {
                 TRY(launch_select(c, rec_base));
@@ -1685,9 +1717,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 ++i;
             }
         }
+        YB_TRACE("round of %u launches queued (p2p seq %llu), waiting", launched, (unsigned long long)c->p2p_seq);
         TRY(fold_stats(c));
         TRY(state_pull(c));
         i = h->iter - rec_base;                              // what the device really selected
+        YB_TRACE("round done: %u merges, halt %u req %u done %u", i, h->halt, h->halt_req, h->done);
         if (c->p2p_pending) {  // (the stream is idle: the pair has completed)
             float xms = 0;
             if (hipEventElapsedTime(&xms, c->p2p_e0, c->p2p_e1) == hipSuccess) {
@@ -1730,7 +1764,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             // ... and agree on what must not differ between them: the batch limit follows the form (any rank sparse: all of
             // them), the candidate list is rebuilt for the longest replica's length
             unsigned long long v[3] = {sig, h->cand_n, want_sparse};
+            YB_TRACE("comm_max3");
             TRY(comm_max3(c, v));
+            YB_TRACE("comm_max3 back");
             if (v[0] != sig) return fail(c, YABPE_E_COMM, "ranks diverged (iter/flags %llx vs max %llx)", sig, v[0]);
             cand_n_all = (uint32_t)v[1];
             want_sparse = v[2];
@@ -1755,17 +1791,32 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                     if (c->xeff < c->xcap) {
                         c->xeff = (uint32_t)std::min<uint64_t>(c->xcap, 4ull * c->xeff);  // (the buffers hold more: no reallocation)
                     } else {
+                        YB_TRACE("comm_buffers %u -> %u", c->xcap, c->xcap * 4);
                         TRY(comm_buffers(c, c->xcap * 4));
                     }
                     c->exchange_growths++;
                 }
+                YB_TRACE("table_rebuild (delta_full %d)", (int)delta_full);
                 TRY(table_rebuild(c, delta_full ? c->table_cap : c->table_cap * 4));
+                YB_TRACE("table_rebuild back");
                 TRY(state_pull(c));
                 i = h->iter - rec_base;  // resume after the last recorded merge
                 while (ev_next > 0 && c->events[ev_next - 1].iter_rel >= i) --ev_next;
                 continue;
             }
-            if (h->halt == HALT_COMM) return fail(c, YABPE_E_COMM, "a peer's records did not arrive within the time limit (peer-to-peer exchange) after %u merges", h->iter - rec_base);
+            if (h->halt == HALT_COMM) {
+                // what this rank's receive area holds: the exchange it waited for last, and the flags of both halves per sender
+                std::string seen;
+                if (c->p2p && c->p2p_area) {
+                    std::vector<unsigned long long> fl(2 * (size_t)c->n_ranks);
+                    if (hipMemcpy(fl.data(), c->p2p_area + c->p2p_flags_off, fl.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                        for (size_t q = 0; q < fl.size(); ++q) seen += (q ? " " : "") + std::to_string(fl[q]);
+                    else
+                        (void)hipGetLastError();
+                }
+                return fail(c, YABPE_E_COMM, "a peer's records did not arrive within the time limit (peer-to-peer exchange) after %u merges; rank %d launched exchange %llu, "
+                            "flags in its receive area [half][sender]: %s", h->iter - rec_base, c->rank, (unsigned long long)c->p2p_seq, seen.c_str());
+            }
             const char *why = h->halt == HALT_POOL_FULL ? "token byte pool exhausted (option pool_bytes)"
                               : h->halt == HALT_VOCAB_FULL ? "u16 token id space exhausted"
                                                            : "device halt";
@@ -1780,9 +1831,14 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         // 1 GiB job: 1.60 s at 50-70 % load, 1.42 s at 12-30 %), and the table is scanned only now and then (candidate
         // rebuilds).  Same decision on every rank.
         if (h->table_entries * 100 > c->table_cap * (uint64_t)optv(c, "table_load_pct", 30))
+        {
+            YB_TRACE("table_grow");
             TRY(table_grow(c, std::max<uint64_t>(h->table_entries * (uint64_t)std::max<int64_t>(2, optv(c, "table_grow_x", 8)), 1ull << 16)));
+            YB_TRACE("table_grow back");
+        }
         if (c->n_tiles >= retile_min_tiles && !c->weighted &&
             (double)h->live_slots < retile_frac * (double)c->n_tiles * SPAN) {
+            YB_TRACE("retile");
             TRY(retile_flat(c));
         }
     }
@@ -1830,6 +1886,18 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->stats.algo_bytes_total += 2 * (T_ + c->n_words_input);
             T_ -= c->log_sites[k];
         }
+        // the streaming phase as a whole: its launches, the merges they applied, their algorithmic bytes; a launch applies a batch,
+        // so the event-timed launches get the phase's bytes per launch (merge indices of sampled launches are lower bounds)
+        if (!split_marked) dense_applied = n - std::min<uint32_t>(n, (c->pending && !h->done) ? h->n_batch : 0u);
+        dense_applied = std::min(dense_applied, n);
+        uint64_t dense_algo = 0, dense_actual = 0, dense_sampled_now = 0;
+        for (uint32_t k = 0; k < dense_applied; ++k) {
+            dense_algo += 2 * (Ti[k] + c->n_words_input);
+            dense_actual += 2 * c->log_live[k] + 4ull * c->n_tiles;
+        }
+        // (actual: a pass reads the stream once for all the merges of its batch -- the first merge's live slots)
+        c->stats.dense_launches += launches_dense;
+        c->stats.dense_merges += dense_applied;
         for (size_t e = 0; e < ev_next; ++e) {
             uint32_t k = c->events[e].iter_rel;
             if (k >= n) continue;
@@ -1841,11 +1909,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->ev_us.push_back(ems * 1000.0f);
             c->ev_scan_us.push_back(sms * 1000.0f);
             c->stats.apply_launches_sampled += 1;
-            if (!c->events[e].split) {  // streaming form: one pass over the live stream + rewrite (+ selection when fused), one merge
+            if (!c->events[e].split) {  // streaming form: one pass over the live stream + rewrite (+ selection when fused), a batch of merges
                 c->stats.dense_ms_sampled += ems;
-                c->stats.dense_launches_sampled += 1;
-                c->stats.dense_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
-                c->stats.dense_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
+                dense_sampled_now += 1;
             }
             if (c->events[e].split) {  // (sparse form: the merge index of a sampled launch is a lower bound -- launches select batches)
                 c->stats.scan_ms_sampled += sms;
@@ -1855,6 +1921,11 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             }
             c->stats.apply_algo_bytes_sampled += 2 * (Ti[k] + c->n_words_input);
             c->stats.apply_actual_bytes_sampled += 2 * c->log_live[k] + 4ull * c->n_tiles;
+        }
+        if (launches_dense && dense_sampled_now) {
+            c->stats.dense_launches_sampled += dense_sampled_now;
+            c->stats.dense_algo_bytes_sampled += dense_algo * dense_sampled_now / launches_dense;
+            c->stats.dense_actual_bytes_sampled += dense_applied ? dense_actual / dense_applied * dense_sampled_now : 0;  // (one read of the live stream per launch)
         }
     }
     if (n) {

@@ -534,6 +534,7 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
 // left neighbour, or b / c when the neighbour is itself a site; y the right neighbour) -- so the other half indexes one of
 // four small LDS arrays directly: a delta is ONE fire-and-forget LDS add, no hashing, no probing, no peeling of hot keys.
 constexpr int HIST_V = 512; // tokens that may exist while this form is used (the host checks)
+constexpr uint32_t HIST_K_MAX = 4; // merges per launch at most while it is used (one 8 KiB block each, dynamic LDS)
 struct Hist {
     int *h; // [4][HIST_V]: role 0 (x,a), 1 (x,c), 2 (b,y), 3 (c,y)
 };
@@ -2099,8 +2100,8 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
 // wave-level votes (no workgroup barriers), probes the byte-string set for every accepted merge side by side and commits.
 // More than WIN pairs tying at the top, or a first merge whose bytes may exist already (a full byte compare decides), end in
 // a batch of one.
-__device__ __forceinline__ void select_eval(const SelectParams &P) {
-    __shared__ WinEnt s_win[WIN];
+// s_win: LDS for WIN window entries (8 KiB), the caller's -- a kernel whose own tables are dead by now lends them.
+__device__ __forceinline__ void select_eval(const SelectParams &P, WinEnt *s_win) {
     __shared__ AccEnt s_acc[KMAX];
     __shared__ __attribute__((aligned(16))) uint32_t s_hset[2 * WIN]; // (the window's hash set; afterwards the packed sort keys live here)
     __shared__ unsigned long long s_red[WPB], s_fold[2];
@@ -2220,11 +2221,14 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
     // rank walks the same window).  More than WIN of them: a quarter of the distance, again.
     unsigned long long L = 0ull;
     uint32_t n_win = 0;
-    uint32_t wshift = min(max(st->win_shift, 2u), 20u), narrowed = 0;
+    uint32_t wshift = min(max(st->win_shift, 1u), 20u), narrowed = 0;
     if (cmax) {
         unsigned long long delta = kmax > 1u ? min(max((unsigned long long)kmax, cmax >> wshift), 1ull << 31) : 0ull;
         for (int attempt = 0; attempt < 8; ++attempt) {
             L = cmax > delta ? cmax - delta : 1ull;
+            // (never below the list's threshold: only pairs with count >= T are on EVERY replica's list -- a pair below it may be
+            // listed on one rank and not on another, and the window's size decides how far a batch can go)
+            if (kmax > 1u && L < s_lim[0] && cmax >= s_lim[0]) L = s_lim[0];
             auto put = [&](unsigned long long ent, unsigned long long c) {
                 const uint32_t key = (uint32_t)(ent >> 32);
                 uint32_t h = hash32(key) & (HSET - 1u);
@@ -2436,7 +2440,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P) {
         st->cand_n = cand_n;
         if (flag) st->n_batch = 0u;
         // next time: a narrower window after an overflow, a wider one when this one held few pairs
-        if (kmax > 1u) st->win_shift = narrowed ? min(wshift + narrowed, 20u) : (n_win < 4u * kmax && wshift > 2u) ? wshift - 1u : wshift;
+        if (kmax > 1u) st->win_shift = narrowed ? min(wshift + narrowed, 20u) : (n_win < 4u * kmax && wshift > 1u) ? wshift - 1u : wshift;
     }
     flag = __builtin_amdgcn_readfirstlane(flag);
     if (flag) return;
@@ -2777,13 +2781,13 @@ struct FuseParams {
     SelectParams sel;
 };
 // (call it from ONE place per kernel: the selection is ~9 KB of code, and these launches start with a cold instruction cache)
-__device__ __forceinline__ void fused_select_tail(const FuseParams &F) {
+__device__ __forceinline__ void fused_select_tail(const FuseParams &F, WinEnt *win) {
     if (!F.ticket) return;
     YB_SEL_STAMP(0);
     if (!last_workgroup(F.ticket)) return;
     if (threadIdx.x >= BLOCK) return; // (a wider workgroup: the selection is written for BLOCK threads; ended waves are not waited for)
     YB_SEL_STAMP(8);
-    select_eval(F.sel);
+    select_eval(F.sel, win);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_argmax_cand(CandParams P) {
@@ -2827,23 +2831,38 @@ __global__ __launch_bounds__(BLOCK) void k_cand_rebuild(CandParams P) {
     }
 }
 
+// what a workgroup keeps about the merges of the batch (LDS)
+struct BatchLds {
+    uint32_t a[KMAX], b[KMAX], c[KMAX];
+    uint32_t row[KMAX];            // signature block of the pair
+    unsigned long long mask[KMAX]; // its three bits inside the block
+};
+
 // ================================================================ the per-merge launches (they end with the fused selection)
 // ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
 // (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
 // HIST (flat layout, at most HIST_V tokens): the deltas go to the direct-indexed LDS store (Hist) instead of the hashed one.
+// A BATCH of merges per launch here too (DevState::batch, at most `hist_k` of them in the HIST form -- the host sets
+// DevState::kmax accordingly): a tile is read once, the merges are applied to it in batch order while it sits in registers
+// (the DEFER forms of the rewrite) and it is written back once -- one trip of the stream and one wait for the write-back
+// for all of them.  HIST: one direct-indexed block per merge of the batch, in dynamic LDS ([hist_k][4][HIST_V] ints);
+// when the workgroup is through with them the selection's window lives there.
 template <bool WEIGHTED, bool HIST = false>
-__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F, LongParams LW, uint32_t long_first) {
+__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F, LongParams LW, uint32_t long_first, uint32_t hist_k) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     static_assert(!(HIST && WEIGHTED), "the direct-indexed store holds 32-bit deltas");
+    static_assert(sizeof(WinEnt) * WIN <= 4 * HIST_V * sizeof(int), "the selection's window fits one direct-indexed block");
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[]; // HIST: hist_k blocks of [4][HIST_V]
     __shared__ uint32_t s_keys[HIST ? 1 : AGG_N];
     __shared__ AggV s_vals[HIST ? 1 : AGG_N];
-    __shared__ int s_hist[HIST ? 4 * HIST_V : 1];
+    __shared__ WinEnt s_selwin[HIST ? 1 : WIN];
     __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
     __shared__ unsigned long long s_cnt[2];
+    __shared__ BatchLds s_bm;
 
     DevState *st = P.st;
     if (st->done | st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
-    // workgroups [0, apply_blocks) apply the merge; [apply_blocks, long_first) do k_rank_update's work and [long_first, ..) the
+    // workgroups [0, apply_blocks) apply the merges; [apply_blocks, long_first) do k_rank_update's work and [long_first, ..) the
     // long words' (k_apply_long) in the same launch
     if (blockIdx.x >= long_first) {
         apply_long_block(LW, blockIdx.x - long_first);
@@ -2852,12 +2871,23 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     } else {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_hist : nullptr};
-    C.mk = yb_memkey(C.a, C.b);
-    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
-    const uint32_t mk = C.mk;
-    if constexpr (HIST) hist_init(Hist{s_hist}); else agg_init(C.agg);
+    const uint32_t nbatch = __builtin_amdgcn_readfirstlane(min(st->n_batch, HIST ? min(hist_k, (uint32_t)KMAX) : (uint32_t)KMAX));
+    if (threadIdx.x < (uint32_t)KMAX) {
+        BatchMerge m = BatchMerge{0u, 0u, 0u, 0u};
+        if (threadIdx.x < nbatch) m = st->batch[threadIdx.x];
+        s_bm.a[threadIdx.x] = m.a;
+        s_bm.b[threadIdx.x] = m.b;
+        s_bm.c[threadIdx.x] = m.c;
+    }
+    // (the first merge of the batch stays in scalar registers: most launches of this phase apply one or two)
+    const BatchMerge m0 = st->batch[0];
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, 0u, 0u, 0u, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_dyn : nullptr};
+    if constexpr (HIST) {
+        for (uint32_t i = threadIdx.x; i < nbatch * 4u * (uint32_t)HIST_V; i += BLOCK) s_dyn[i] = 0;
+    } else {
+        agg_init(C.agg);
+    }
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     WaveLds &W = s_w[wib];
     wave_lds_init(W, lane);
@@ -2880,36 +2910,58 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t tile = batch + i * stride;
             const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
-            const TileRegs r = nxt;
+            TileRegs rr = nxt;
             if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
             if (len == 0) continue;
-            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
-            const uint32_t na = next_lane(r.va.x, b0);
-            const uint32_t nb = next_lane(r.vb.x, PADPAD);
-            // (nearly every tile of this phase holds the pair: the per-lane candidate masks are computed once, here, and
-            // handed to the rewrite -- a cheaper any-test first would be paid on top of them in almost every tile)
-            const uint32_t pmA = match_mask8(r.va, na, mk), pmB = match_mask8(r.vb, nb, mk);
-            if (!__any((pmA | pmB) != 0u)) continue;
+            uint32_t len_io = len, fc = CAP; // fc: the first slot of the tile that differs from what HBM holds
+#pragma unroll 1
+            for (uint32_t k = 0; k < nbatch; ++k) { // the merges of the batch, in batch order
+                const uint32_t a = k ? __builtin_amdgcn_readfirstlane(s_bm.a[k]) : m0.a, b = k ? __builtin_amdgcn_readfirstlane(s_bm.b[k]) : m0.b;
+                const uint32_t mk = yb_memkey(a, b);
+                // ---- does any adjacent pair of this tile equal (a,b)?
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(rr.vb.x);
+                const uint32_t na = next_lane(rr.va.x, b0);
+                const uint32_t nb = next_lane(rr.vb.x, PADPAD);
+                // (nearly every tile of this phase holds the pair: the per-lane candidate masks are computed once, here, and
+                // handed to the rewrite -- a cheaper any-test first would be paid on top of them in almost every tile)
+                const uint32_t pmA = match_mask8(rr.va, na, mk), pmB = match_mask8(rr.vb, nb, mk);
+                if (!__any((pmA | pmB) != 0u)) continue;
 #ifdef YB_PROFILE_SLOW // [5]: from the end of one rewrite to the start of the next (the wait for the tile, the match)
-            if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
+                if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
 #endif
-            {
-                TileRegs rr = r;
-                uint32_t len_io = len, fc = CAP;
-                slow_tile<WEIGHTED, AggV, HIST, true>(C, W, tile, len_io, rr, na, nb, wave_sites, wave_freed, fc, pmA, pmB);
-            }
+                C.a = a;
+                C.b = b;
+                C.c = k ? __builtin_amdgcn_readfirstlane(s_bm.c[k]) : m0.c;
+                C.mk = mk;
+                C.self = yb_pairkey(a, b); // its count was set to 0 by the selection: never updated here
+                if constexpr (HIST) C.hist = s_dyn + k * 4u * (uint32_t)HIST_V;
+                slow_tile<WEIGHTED, AggV, HIST, true, true>(C, W, tile, len_io, rr, na, nb, wave_sites, wave_freed, fc, pmA, pmB);
 #ifdef YB_PROFILE_SLOW
-            t_end = __builtin_readcyclecounter();
+                t_end = __builtin_readcyclecounter();
 #endif
+            }
+            if (fc < (uint32_t)CAP) { // write the tile back: the 16-B groups from the first changed slot to the end of what is live
+                const uint32_t pad_end = (len_io + 7u) & ~7u;
+                uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
+                const uint32_t gA = (uint32_t)lane * 8u, gB = 512u + (uint32_t)lane * 8u;
+                if (gA + 8u > fc && gA < pad_end) wb[lane] = rr.va;
+                if (gB + 8u > fc && gB < pad_end) wb[64 + lane] = rr.vb;
+                if (lane == 0) P.tile_len[tile] = len_io;
+            }
         }
     }
 #ifdef YB_PROFILE_SLOW
     if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
 #endif
-    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, HIST ? s_hist : nullptr, C.a, C.b, C.c);
+    if constexpr (HIST) {
+        apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, s_dyn, m0.a, m0.b, m0.c);
+        for (uint32_t k = 1; k < nbatch; ++k) // (the other merges' blocks; flush_entries ends on a barrier)
+            hist_flush(Hist{s_dyn + k * 4u * (uint32_t)HIST_V}, s_bm.a[k], s_bm.b[k], s_bm.c[k], P.out, st);
+    } else {
+        apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
     }
-    fused_select_tail(F);
+    }
+    fused_select_tail(F, HIST ? reinterpret_cast<WinEnt *>(s_dyn) : s_selwin);
 }
 
 // ---------------------------------------------------------------- sparse form: skip index + rewrite, a BATCH of merges per launch
@@ -2948,13 +3000,6 @@ struct ScanSkipParams {
     FuseParams F;                 // ticket != NULL: the workgroup that finishes last selects the next batch
     LongParams LW;                // the long words ride along too: workgroups [long_first, gridDim.x) (k_apply_long's work)
     uint32_t long_first;
-};
-
-// what a workgroup keeps about the merges of the batch (LDS)
-struct BatchLds {
-    uint32_t a[KMAX], b[KMAX], c[KMAX];
-    uint32_t row[KMAX];            // signature block of the pair
-    unsigned long long mask[KMAX]; // its three bits inside the block
 };
 
 template <bool WEIGHTED, int NW>
@@ -3141,8 +3186,9 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
 // for the argument segment first -- one dependent trip less in front of every launch.
 template <bool WEIGHTED, int NW = WPB>
 __global__ __launch_bounds__(NW * 64, NW == WPB ? 3 : 16 / NW) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (<= 128 VGPRs, 16 waves per CU)
+    __shared__ WinEnt s_selwin[WIN];
     if (!scan_skip_block<WEIGHTED, NW>(st, Q)) return;
-    fused_select_tail(Q.F);
+    fused_select_tail(Q.F, s_selwin);
 }
 
 // ================================================================ table growth: re-insert live entries (count != 0)
@@ -3215,7 +3261,8 @@ __global__ __launch_bounds__(BLOCK) void k_delta_apply(DeltaApplyParams P) {
     }
     __syncthreads();
     agg_flush<unsigned long long, BLOCK>(agg, P.table, P.st);
-    fused_select_tail(P.F);
+    __shared__ WinEnt s_selwin[WIN];
+    fused_select_tail(P.F, s_selwin);
 }
 
 // ---------------------------------------------------------------- peer-to-peer exchange (instead of the all-gather)
@@ -3261,7 +3308,9 @@ __global__ __launch_bounds__(BLOCK) void k_xchg_push(XchgParams P) {
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(const_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < P.seq) {
             __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > P.timeout_ticks) { // a peer is gone: stop the job instead of hanging the device
+            // a peer is gone: stop the job instead of hanging the device -- and the exchanges queued behind this one do not wait again
+            if (ld_coherent(&P.st->halt_req) == (uint32_t)HALT_COMM) break;
+            if (wall_clock64() - t0 > P.timeout_ticks) {
                 atomicMax(&P.st->halt_req, (uint32_t)HALT_COMM);
                 break;
             }

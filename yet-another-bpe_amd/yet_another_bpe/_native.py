@@ -42,7 +42,8 @@ class Stats(ctypes.Structure):
             "scan_launches_sampled", "scan_algo_bytes_sampled", "scan_actual_bytes_sampled", "scan_skip_launches", "scan_skip_tiles_read", "cand_rebuilds", "cand_rescans", "fused_launches")] + [
         ("dense_ms_sampled", c_double)] + [(n, c_uint64) for n in ("dense_launches_sampled", "dense_algo_bytes_sampled", "dense_actual_bytes_sampled")] + [
         ("sparse_ms", c_double), ("sparse_merges", c_uint64), ("tail_ms", c_double), ("tail_merges", c_uint64)] + [
-        (n, c_uint64) for n in ("exchanges", "exchange_bytes", "exchange_cap_records", "exchange_growths", "exchange_max_records", "sparse_launches", "tail_launches")] + [("exchange_ms_sampled", c_double), ("exchanges_sampled", c_uint64), ("exchange_p2p", c_uint64)]
+        (n, c_uint64) for n in ("exchanges", "exchange_bytes", "exchange_cap_records", "exchange_growths", "exchange_max_records", "sparse_launches", "tail_launches")] + [("exchange_ms_sampled", c_double), ("exchanges_sampled", c_uint64), ("exchange_p2p", c_uint64),
+        ("dense_launches", c_uint64), ("dense_merges", c_uint64)]
 
 
 class Latency(ctypes.Structure):
