@@ -205,9 +205,10 @@ def main() -> None:
                                    "(exchange_launch_us_sampled: its device time, one per round of launches, waiting for the slowest peer included); "
                                    "otherwise an RCCL all-gather of [header | records] on the compute stream (YABPE_P2P=0, or a rank could not map a peer)"}
     # ---- what bounds the timed job.  It has two phases:
-    #   streaming (the first few hundred merges, most tiles change): ONE fused launch per merge, k_apply -- a coalesced read of
-    #   the whole live token stream + rewrite + pair-table update + the selection of the next merge.  HBM-bound by design:
-    #   `roofline` = sum of A_i = 2 (T_i + W) over its event-timed launches / their summed time (whole iterations).
+    #   streaming (the first few dozen merges, most tiles change): ONE fused launch per selection (a batch of up to two merges, in this
+    #   corpus nearly always one), k_apply -- a coalesced read of the whole live token stream + rewrite + pair-table update + the selection of
+    #   the next merges.  HBM-bound by design: `roofline` = the phase's A_i = 2 (T_i + W) per launch / the event-timed launches' average
+    #   duration (whole iterations).
     #   sparse (the rest: a tile-level skip index finds the ~1 % of the tiles that hold a pair): ONE fused launch per BATCH of
     #   merges (the selection fixes up to 16 consecutive merges it can prove independent), k_scan_skip -- a chain of dependent
     #   memory trips per launch, not a streaming kernel.  `latency` = its measured time per launch against a floor built from
@@ -220,16 +221,19 @@ def main() -> None:
         algo, actual = st["dense_algo_bytes_sampled"], st["dense_actual_bytes_sampled"]
         achieved = algo / secs / 1e9
         out["roofline"] = {
-            "kernel": "k_apply<false,true> (fused per-merge launch of the streaming phase: scan + rewrite + table update + selection)", "bound": "hbm",
+            "kernel": "k_apply<false,true> (fused launch of the streaming phase: one pass over the stream applies the merges the last selection "
+                      "batched -- scan + rewrite + table update + selection)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "launches_timed": n_l, "avg_launch_us": round(1e6 * secs / n_l, 2), "algo_bytes_per_launch": algo // n_l,
+            "launches": st["dense_launches"], "merges": st["dense_merges"], "merges_per_launch": round(st["dense_merges"] / max(1, st["dense_launches"]), 3),
             "actual_stream_bytes_per_launch": actual // n_l, "actual_stream_GBps": round(actual / secs / 1e9, 1),
             "share_of_merge_loop_time": round(phase_ms["streaming"] / max(st["train_ms"], 1e-9), 4),
             "measured_on": f"the timed job itself: every {args.event_sample_dense}th launch of its streaming phase "
                            f"({st['merges_done'] - st['sparse_merges']} merges), HIP events on the library's stream",
-            "note": "achieved = sum of 2*(T_i+W) over the timed launches / their summed duration, whole iterations (T_i live tokens, W words; "
-                    "SURVEY 8d); actual_* = the u16 slots really read (single-token words leave the stream).  traffic: PMC counters cannot be "
+            "note": "achieved = algorithmic bytes per launch / average launch duration: sum of 2*(T_i+W) over the merges the phase's launches applied "
+                    "/ its launches (a launch applies merges_per_launch merges in one pass), over the average of the event-timed launches, whole iterations "
+                    "(T_i live tokens, W words; SURVEY 8d); actual_* = the u16 slots really read (single-token words leave the stream).  traffic: PMC counters cannot be "
                     "collected inside this run; the rocprofv3 --pmc summary for this kernel is kept under profiles/ (see traffic_profile)",
         }
         pmc = sorted((REPO / "profiles").glob("r*_pmc_k_apply_summary.json"))

@@ -1371,15 +1371,12 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             const FuseParams F = fuse_params(apply_grid);
             const uint32_t rr_blocks = rank_rides ? rank_blocks : 0u;
             c->blk_used = std::max(c->blk_used, apply_grid);
-            // (direct-indexed delta store: one LDS block per merge of the batch -- DevState::kmax is what a selection may take)
-            const uint32_t hist_k = std::max(1u, c->kmax_now);
             if (c->weighted)
-                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks, 0u);
-            else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V && hist_k <= HIST_K_MAX)  // (every token id this launch can meet indexes the direct store)
-                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), hist_k * 4u * HIST_V * sizeof(int), c->stream, P, apply_grid, R, F, LW,
-                                   apply_grid + rr_blocks, hist_k);
+                hipLaunchKernelGGL(k_apply<true>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
+            else if (optv(c, "hist", 1) && tokens_upper <= (uint32_t)HIST_V)  // (every token id this launch can meet indexes the direct store)
+                hipLaunchKernelGGL((k_apply<false, true>), dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
             else
-                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks, 0u);
+                hipLaunchKernelGGL(k_apply<false>, dim3(apply_grid + rr_blocks + long_blocks), dim3(BLOCK), 0, c->stream, P, apply_grid, R, F, LW, apply_grid + rr_blocks);
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));
         } else {
             // sparse form: skip index + rewrite of the tiles that pass, a batch of merges per launch.
@@ -1521,6 +1518,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     h->halt = 0;
     h->halt_req = 0;
     h->n_batch = 0;
+    h->n_select = 0;
     h->batch_others = 0;
     h->kmax = 1;
     h->win_shift = 3;
@@ -1587,7 +1585,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
     bool skip_cand_once = false;
     bool first_round = true;
     unsigned long long prev_best = 0;
-    uint64_t launches_sparse = 0, launches_at_tail = 0, launches_dense = 0;
+    uint64_t launches_sparse = 0, launches_at_tail = 0, launches_dense = 0, launch_no = 0;
     uint32_t dense_applied = 0;  // merges the streaming launches applied (what was selected when the form changed, less the pending batch)
     uint32_t cand_n_all = 0;  // length of the candidate list at the last read (multi-GPU: of the longest replica's)
     bool sparse_global = false;  // the sparse form has been called for (by any rank)
@@ -1620,6 +1618,7 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             split_marked = true;
             split_at = i;
             dense_applied = i - std::min<uint32_t>(i, c->pending ? h->n_batch : 0u);
+            launches_dense = h->n_select - std::min<uint32_t>(h->n_select, c->pending ? 1u : 0u);  // (selections that committed a batch = launches with work; launches queued behind a stop flag return at once)
             HIPCHK(c, hipEventRecord(T.t_split, c->stream));
         }
         if (skip_cand_once) {  // the last batch hit HALT_RESCAN: finish it with the full scan
@@ -1660,9 +1659,10 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 c->sig_built_at = i;
             }
         }
-        // merges one selection may take: a batch in either form (the streaming form's direct-indexed delta store holds one LDS
-        // block per merge: two keep four workgroups per CU)
-        const uint32_t kmax = (uint32_t)std::max<int64_t>(1, sparse_now ? std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX)) : std::min<int64_t>(HIST_K_MAX, optv(c, "batch_max_stream", 2)));
+        // merges one selection may take: a batch in the sparse form.  The streaming form applies one merge per pass: a pass that
+        // applies a batch was built and measured (DESIGN (c)) -- a tenth slower per pass, and the first merges of a job hardly ever
+        // batch (they are the consecutive pairs of the most frequent words: rule (1))
+        const uint32_t kmax = sparse_now ? (uint32_t)std::max<int64_t>(1, std::min<int64_t>(KMAX, optv(c, "batch_max", KMAX))) : 1u;
         if (kmax != c->kmax_now) {
             HIPCHK(c, hipMemcpyAsync(&c->st->kmax, &kmax, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             c->kmax_now = kmax;
@@ -1673,9 +1673,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         first_round = false;
         c->rec_n_live = i;
         TRY(ensure_records((uint32_t)std::min<uint64_t>(num_merges, (uint64_t)i + (uint64_t)(n_launch + 2) * kmax)));
-        auto sample = [&](uint32_t iter_rel) -> EventPair * {
+        auto sample = [&](uint32_t iter_rel) -> EventPair * {  // (every Nth LAUNCH; iter_rel: the merges selected so far, a lower bound in the fused forms)
             const uint32_t every = c->split_mode ? ev_sample : ev_sample_dense;
-            if (!every || (iter_rel % every) != 0) return nullptr;
+            if (!every || (launch_no++ % every) != 0) return nullptr;
             if (ev_next == c->events.size()) {
                 EventPair n{};
                 if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess || hipEventCreate(&n.e2) != hipSuccess) return nullptr;
@@ -1709,7 +1709,6 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
                 const bool last = i >= num_merges;
                 TRY(launch_apply(c, rec_base, tok_upper, apply_grid, sample(i - 1), true));
                 if (kmax == 1) ++i; else if (sparse_now) ++launches_sparse;  // (a batch per launch: i stays a lower bound until the next read)
-                if (!sparse_now) ++launches_dense;
                 if (last) break;
             } else {
                 TRY(launch_select(c, rec_base));
@@ -1888,7 +1887,10 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
         }
         // the streaming phase as a whole: its launches, the merges they applied, their algorithmic bytes; a launch applies a batch,
         // so the event-timed launches get the phase's bytes per launch (merge indices of sampled launches are lower bounds)
-        if (!split_marked) dense_applied = n - std::min<uint32_t>(n, (c->pending && !h->done) ? h->n_batch : 0u);
+        if (!split_marked) {
+            dense_applied = n - std::min<uint32_t>(n, (c->pending && !h->done) ? h->n_batch : 0u);
+            launches_dense = h->n_select - std::min<uint32_t>(h->n_select, (c->pending && !h->done) ? 1u : 0u);
+        }
         dense_applied = std::min(dense_applied, n);
         uint64_t dense_algo = 0, dense_actual = 0, dense_sampled_now = 0;
         for (uint32_t k = 0; k < dense_applied; ++k) {
@@ -1909,7 +1911,9 @@ int yabpe_train(yabpe_ctx *c, uint32_t num_merges, uint64_t min_frequency, uint3
             c->ev_us.push_back(ems * 1000.0f);
             c->ev_scan_us.push_back(sms * 1000.0f);
             c->stats.apply_launches_sampled += 1;
-            if (!c->events[e].split) {  // streaming form: one pass over the live stream + rewrite (+ selection when fused), a batch of merges
+            // streaming form: one pass over the live stream + rewrite (+ selection when fused), a batch of merges.  (A launch queued
+            // behind a stop flag -- the rest of a round after a rescan request -- returns in microseconds: not a pass.)
+            if (!c->events[e].split && ems >= 0.02f) {
                 c->stats.dense_ms_sampled += ems;
                 dense_sampled_now += 1;
             }

@@ -73,6 +73,7 @@ struct DevState {
                                    // every rank of a multi-GPU job keeps the same value
     unsigned long long batch_others; // sum of the counts of batch[0 .. n_batch - 1): the sites those merges have in the flat layout
     uint32_t n_batch;              // merges selected and not applied yet: batch[0 .. n_batch), in selection order; a, b, c above = batch[0]
+    uint32_t n_select;             // selections that committed a batch so far (= apply launches that had work to do, plus the pending one)
     BatchMerge batch[KMAX];
 };
 
@@ -534,7 +535,6 @@ __device__ __forceinline__ void agg_flush(Agg<V> g, const PairTable &t, DevState
 // left neighbour, or b / c when the neighbour is itself a site; y the right neighbour) -- so the other half indexes one of
 // four small LDS arrays directly: a delta is ONE fire-and-forget LDS add, no hashing, no probing, no peeling of hot keys.
 constexpr int HIST_V = 512; // tokens that may exist while this form is used (the host checks)
-constexpr uint32_t HIST_K_MAX = 4; // merges per launch at most while it is used (one 8 KiB block each, dynamic LDS)
 struct Hist {
     int *h; // [4][HIST_V]: role 0 (x,a), 1 (x,c), 2 (b,y), 3 (c,y)
 };
@@ -2081,6 +2081,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P) {
             st->c_is_new = is_new;
             st->batch[0] = BatchMerge{x, y, cid, is_new};
             st->n_batch = 1u;
+            st->n_select = st->n_select + 1u;
             st->batch_others = 0ull;
             st->iter = d_iter + 1;
             st->pool_used = is_new ? ((pu + L + 3u) & ~3u) : pu;
@@ -2532,6 +2533,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P, WinEnt *s_win
             st->n_tokens = cid + 1u;
             st->iter = it0 + keep;
             st->n_batch = keep;
+            st->n_select = st->n_select + 1u;
             st->batch_others = others_sum;
             st->best_count = s_win[wk].cnt; // (the host's heuristics look at the lowest count selected so far)
 #ifdef YB_PROFILE_LAUNCH
@@ -2614,6 +2616,7 @@ __device__ __forceinline__ void select_eval(const SelectParams &P, WinEnt *s_win
                 st->best_count = s_win[w].cnt;
                 st->batch[0] = BatchMerge{x, y, cid, is_new};
                 st->n_batch = 1u;
+                st->n_select = st->n_select + 1u;
                 st->batch_others = 0ull;
                 st->iter = it0 + 1u;
                 st->pool_used = is_new ? ((pool0 + Lm + 3u) & ~3u) : pool0;
@@ -2842,27 +2845,19 @@ struct BatchLds {
 // ---------------------------------------------------------------- fused form: scan + rewrite in one kernel
 // (used while sites are dense: nearly every tile changes, a second read of the stream would cost more)
 // HIST (flat layout, at most HIST_V tokens): the deltas go to the direct-indexed LDS store (Hist) instead of the hashed one.
-// A BATCH of merges per launch here too (DevState::batch, at most `hist_k` of them in the HIST form -- the host sets
-// DevState::kmax accordingly): a tile is read once, the merges are applied to it in batch order while it sits in registers
-// (the DEFER forms of the rewrite) and it is written back once -- one trip of the stream and one wait for the write-back
-// for all of them.  HIST: one direct-indexed block per merge of the batch, in dynamic LDS ([hist_k][4][HIST_V] ints);
-// when the workgroup is through with them the selection's window lives there.
 template <bool WEIGHTED, bool HIST = false>
-__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F, LongParams LW, uint32_t long_first, uint32_t hist_k) {
+__global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_blocks, RankParams R, FuseParams F, LongParams LW, uint32_t long_first) {
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     static_assert(!(HIST && WEIGHTED), "the direct-indexed store holds 32-bit deltas");
-    static_assert(sizeof(WinEnt) * WIN <= 4 * HIST_V * sizeof(int), "the selection's window fits one direct-indexed block");
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[]; // HIST: hist_k blocks of [4][HIST_V]
     __shared__ uint32_t s_keys[HIST ? 1 : AGG_N];
     __shared__ AggV s_vals[HIST ? 1 : AGG_N];
-    __shared__ WinEnt s_selwin[HIST ? 1 : WIN];
+    __shared__ int s_hist[HIST ? 4 * HIST_V : 1];
     __shared__ __attribute__((aligned(16))) WaveLds s_w[WPB];
     __shared__ unsigned long long s_cnt[2];
-    __shared__ BatchLds s_bm;
 
     DevState *st = P.st;
     if (st->done | st->halt) return; // (the same answer in every workgroup: nobody takes a ticket)
-    // workgroups [0, apply_blocks) apply the merges; [apply_blocks, long_first) do k_rank_update's work and [long_first, ..) the
+    // workgroups [0, apply_blocks) apply the merge; [apply_blocks, long_first) do k_rank_update's work and [long_first, ..) the
     // long words' (k_apply_long) in the same launch
     if (blockIdx.x >= long_first) {
         apply_long_block(LW, blockIdx.x - long_first);
@@ -2871,23 +2866,12 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
     } else {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nbatch = __builtin_amdgcn_readfirstlane(min(st->n_batch, HIST ? min(hist_k, (uint32_t)KMAX) : (uint32_t)KMAX));
-    if (threadIdx.x < (uint32_t)KMAX) {
-        BatchMerge m = BatchMerge{0u, 0u, 0u, 0u};
-        if (threadIdx.x < nbatch) m = st->batch[threadIdx.x];
-        s_bm.a[threadIdx.x] = m.a;
-        s_bm.b[threadIdx.x] = m.b;
-        s_bm.c[threadIdx.x] = m.c;
-    }
-    // (the first merge of the batch stays in scalar registers: most launches of this phase apply one or two)
-    const BatchMerge m0 = st->batch[0];
-    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, 0u, 0u, 0u, 0u, 0u, lane,
-                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_dyn : nullptr};
-    if constexpr (HIST) {
-        for (uint32_t i = threadIdx.x; i < nbatch * 4u * (uint32_t)HIST_V; i += BLOCK) s_dyn[i] = 0;
-    } else {
-        agg_init(C.agg);
-    }
+    SlowCtx<AggV> C{P, Agg<AggV>{s_keys, s_vals, HIST ? 0u : (uint32_t)AGG_N - 1u}, st, st->a, st->b, st->c, 0u, 0u, lane,
+                    KeyMemo{{EMPTY, EMPTY, EMPTY, EMPTY}, {0u, 0u, 0u, 0u}}, HIST ? s_hist : nullptr};
+    C.mk = yb_memkey(C.a, C.b);
+    C.self = yb_pairkey(C.a, C.b); // its count was set to 0 by k_select: never updated here
+    const uint32_t mk = C.mk;
+    if constexpr (HIST) hist_init(Hist{s_hist}); else agg_init(C.agg);
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     WaveLds &W = s_w[wib];
     wave_lds_init(W, lane);
@@ -2910,58 +2894,37 @@ __global__ __launch_bounds__(BLOCK) void k_apply(ApplyParams P, uint32_t apply_b
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t tile = batch + i * stride;
             const uint32_t len = __builtin_amdgcn_readlane(my_len, i);
-            TileRegs rr = nxt;
+            const TileRegs r = nxt;
             if (i + 1 < cnt) nxt = load_tile(P.tiles, tile + stride, __builtin_amdgcn_readlane(my_len, i + 1), lane);
             if (len == 0) continue;
-            uint32_t len_io = len, fc = CAP; // fc: the first slot of the tile that differs from what HBM holds
-#pragma unroll 1
-            for (uint32_t k = 0; k < nbatch; ++k) { // the merges of the batch, in batch order
-                const uint32_t a = k ? __builtin_amdgcn_readfirstlane(s_bm.a[k]) : m0.a, b = k ? __builtin_amdgcn_readfirstlane(s_bm.b[k]) : m0.b;
-                const uint32_t mk = yb_memkey(a, b);
-                // ---- does any adjacent pair of this tile equal (a,b)?
-                const uint32_t b0 = __builtin_amdgcn_readfirstlane(rr.vb.x);
-                const uint32_t na = next_lane(rr.va.x, b0);
-                const uint32_t nb = next_lane(rr.vb.x, PADPAD);
-                // (nearly every tile of this phase holds the pair: the per-lane candidate masks are computed once, here, and
-                // handed to the rewrite -- a cheaper any-test first would be paid on top of them in almost every tile)
-                const uint32_t pmA = match_mask8(rr.va, na, mk), pmB = match_mask8(rr.vb, nb, mk);
-                if (!__any((pmA | pmB) != 0u)) continue;
+            // ---- fast path: does any adjacent pair of this tile equal (a,b)?
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.vb.x);
+            const uint32_t na = next_lane(r.va.x, b0);
+            const uint32_t nb = next_lane(r.vb.x, PADPAD);
+            // (nearly every tile of this phase holds the pair: the per-lane candidate masks are computed once, here, and
+            // handed to the rewrite -- a cheaper any-test first would be paid on top of them in almost every tile)
+            const uint32_t pmA = match_mask8(r.va, na, mk), pmB = match_mask8(r.vb, nb, mk);
+            if (!__any((pmA | pmB) != 0u)) continue;
 #ifdef YB_PROFILE_SLOW // [5]: from the end of one rewrite to the start of the next (the wait for the tile, the match)
-                if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
+            if (lane == 0 && t_end) W.prof[5] += __builtin_readcyclecounter() - t_end;
 #endif
-                C.a = a;
-                C.b = b;
-                C.c = k ? __builtin_amdgcn_readfirstlane(s_bm.c[k]) : m0.c;
-                C.mk = mk;
-                C.self = yb_pairkey(a, b); // its count was set to 0 by the selection: never updated here
-                if constexpr (HIST) C.hist = s_dyn + k * 4u * (uint32_t)HIST_V;
-                slow_tile<WEIGHTED, AggV, HIST, true, true>(C, W, tile, len_io, rr, na, nb, wave_sites, wave_freed, fc, pmA, pmB);
+            {
+                TileRegs rr = r;
+                uint32_t len_io = len, fc = CAP;
+                slow_tile<WEIGHTED, AggV, HIST, true>(C, W, tile, len_io, rr, na, nb, wave_sites, wave_freed, fc, pmA, pmB);
+            }
 #ifdef YB_PROFILE_SLOW
-                t_end = __builtin_readcyclecounter();
+            t_end = __builtin_readcyclecounter();
 #endif
-            }
-            if (fc < (uint32_t)CAP) { // write the tile back: the 16-B groups from the first changed slot to the end of what is live
-                const uint32_t pad_end = (len_io + 7u) & ~7u;
-                uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-                const uint32_t gA = (uint32_t)lane * 8u, gB = 512u + (uint32_t)lane * 8u;
-                if (gA + 8u > fc && gA < pad_end) wb[lane] = rr.va;
-                if (gB + 8u > fc && gB < pad_end) wb[64 + lane] = rr.vb;
-                if (lane == 0) P.tile_len[tile] = len_io;
-            }
         }
     }
 #ifdef YB_PROFILE_SLOW
     if (lane < 8 && W.prof[lane]) atomicAdd(&g_slow_prof[lane], W.prof[lane]);
 #endif
-    if constexpr (HIST) {
-        apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, s_dyn, m0.a, m0.b, m0.c);
-        for (uint32_t k = 1; k < nbatch; ++k) // (the other merges' blocks; flush_entries ends on a barrier)
-            hist_flush(Hist{s_dyn + k * 4u * (uint32_t)HIST_V}, s_bm.a[k], s_bm.b[k], s_bm.c[k], P.out, st);
-    } else {
-        apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane);
+    apply_epilogue(P, C.agg, st, s_cnt, wave_sites, wave_freed, lane, HIST ? s_hist : nullptr, C.a, C.b, C.c);
     }
-    }
-    fused_select_tail(F, HIST ? reinterpret_cast<WinEnt *>(s_dyn) : s_selwin);
+    __shared__ WinEnt s_selwin[WIN];
+    fused_select_tail(F, s_selwin);
 }
 
 // ---------------------------------------------------------------- sparse form: skip index + rewrite, a BATCH of merges per launch
