@@ -241,12 +241,13 @@ def main() -> None:
             d = json.loads(pmc[-1].read_text())
             tb = int(d["traffic_bytes_per_launch"])
             out["roofline"]["traffic"] = tb
+            out["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}: a committed rocprofv3 --pmc profile of this kernel on this workload, NOT measured in this run"
             out["roofline"]["traffic_profile"] = {
                 "file": f"profiles/{pmc[-1].name}", "traffic_bytes_per_launch": tb,
                 "traffic_GBps_at_this_runs_launch_time": round(tb / (secs / n_l) / 1e9, 1), "traffic_frac_of_peak": round(tb / (secs / n_l) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "`traffic` comes from that committed rocprofv3 --pmc profile of the same kernel on the same workload (tools/collect_pmc.sh), NOT "
-                        "from this run.  It is 1.54 x the algorithmic bytes: the stream is read once (2.2 GB) and the rewrite writes back every "
-                        "tile from its first changed slot on (1.16 GB) -- in the first merges nearly every tile changes, so the algorithmic figure "
+                        f"from this run.  It is {tb / max(1, algo // n_l):.2f} x the algorithmic bytes: the stream is read once and the rewrite writes back every "
+                        "tile from its first changed slot on -- in the first merges nearly every tile changes, so the algorithmic figure "
                         "(reads of live tokens only) cannot be met by any in-place rewrite; against the bytes the kernel has to move the launch "
                         "runs at the traffic_frac_of_peak given here"}
     if st["sparse_merges"] and rank == 0:

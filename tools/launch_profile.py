@@ -30,7 +30,7 @@ with _native.Context() as g:
         sh = np.zeros(65536, dtype=np.uint64)
         L.yabpe_debug_stop_hist(ctypes.c_void_p(sh.ctypes.data))
 raw = out.reshape(65536, 4)
-names = {0: "-", 1: "rule 1 (token consumed)", 2: "rule 2 (tie may come first)", 3: "below list threshold", 4: "limit", 5: "window end", 6: "run merge"}
+names = {0: "-", 1: "batch rule (1) / (2) or a count below the threshold", 4: "limit", 5: "window end", 6: "run merge"}
 for lo, hi in [(80, 300), (300, 1000), (1000, 3000), (3000, 12000), (12000, 32000)]:
     v = sh[lo:hi]; v = v[v != 0]
     if len(v) == 0: continue
