@@ -3070,6 +3070,20 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
             const uint2 v = s_list[idx];
             return make_uint2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
         };
+        // (a rewritten tile is written back when the NEXT tile's registers have been taken: the wave has to wait for everything it
+        // has in flight before it can use a prefetched tile (vmcnt counts in order), and stores issued just before that wait are
+        // waited for in full -- ~900 cycles per tile; issued a tile earlier they are long acknowledged)
+        TileRegs pend = TileRegs{make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+        uint32_t pend_tile = 0, pend_len = 0, pend_fc = CAP;
+        auto write_back = [&](const TileRegs &t, uint32_t tile_, uint32_t len_, uint32_t fc_) {
+            // the 16-B groups from the first changed slot to the end of what is live
+            const uint32_t pad_end = (len_ + 7u) & ~7u;
+            uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile_ * CAP);
+            const uint32_t gA = (uint32_t)lane * 8u, gB = 512u + (uint32_t)lane * 8u;
+            if (gA + 8u > fc_ && gA < pad_end) wb[lane] = t.va;
+            if (gB + 8u > fc_ && gB < pad_end) wb[64 + lane] = t.vb;
+            if (lane == 0) P.tile_len[tile_] = len_;
+        };
         uint32_t j = wib;
         uint2 it0 = j < n ? list_at(j) : make_uint2(0u, 0u);
         TileRegs q0 = load_tile(P.tiles, it0.x, it0.y & 0xffffu, lane);
@@ -3077,6 +3091,12 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
             const uint32_t tile = it0.x;
             uint32_t tlen = it0.y & 0xffffu, kmask = it0.y >> 16;
             TileRegs r = q0;
+            asm volatile("" : "+v"(r.va.x), "+v"(r.vb.x)); // (the prefetched registers are taken HERE: in front of the stores below)
+            if (pend_fc < (uint32_t)CAP) {
+                write_back(pend, pend_tile, pend_len, pend_fc);
+                pend_fc = CAP;
+            }
+            asm volatile("" ::: "memory"); // (the stores stay here: their registers are free for the next prefetch)
             j += NW;
             if (j < n) { // (one candidate ahead: a second one in flight cost the flat form its fourth wave per SIMD)
                 it0 = list_at(j);
@@ -3119,16 +3139,15 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
                     slow_tile<WEIGHTED, AggV, false, false, true>(C, W, tile, tlen, r, na, nb, wave_sites, wave_freed, first_changed);
                 }
             }
-            if (first_changed < (uint32_t)CAP) { // write the tile back: the 16-B groups from the first changed slot to the end of what is live
-                const uint32_t pad_end = (tlen + 7u) & ~7u;
-                uint4 *wb = reinterpret_cast<uint4 *>(P.tiles + (size_t)tile * CAP);
-                const uint32_t gA = (uint32_t)lane * 8u, gB = 512u + (uint32_t)lane * 8u;
-                if (gA + 8u > first_changed && gA < pad_end) wb[lane] = r.va;
-                if (gB + 8u > first_changed && gB < pad_end) wb[64 + lane] = r.vb;
-                if (lane == 0) P.tile_len[tile] = tlen;
-                (void)len_in;
-            }
+            // to be written back, if anything changed (see above; assigned on every path: the registers of the tile before are dead
+            // while a tile is rewritten)
+            pend = r;
+            pend_tile = tile;
+            pend_len = tlen;
+            pend_fc = first_changed;
+            (void)len_in;
         }
+        if (pend_fc < (uint32_t)CAP) write_back(pend, pend_tile, pend_len, pend_fc);
         __syncthreads();
         YB_SCAN_STAMP(2);
 #ifdef YB_PROFILE_SCAN
