@@ -915,9 +915,13 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
     }
 
     YB_SS_STAMP(1);
-    // (order: the stores go out FIRST -- the signature bits and the LDS deltas below run while they are acknowledged; the
-    // candidate loop cannot take the next tile's prefetched registers before this wave's outstanding stores are back,
-    // the in-order vmcnt leaves the compiler no other choice)
+    // The two pairs this site creates will be present in the tile: one signature word each, set by lanes 0 and 1 -- FIRST, as
+    // soon as the neighbours are known: these are the wave's only memory operations here (DEFER form), and the candidate loop
+    // cannot take the next tile's prefetched registers before they are acknowledged (the in-order vmcnt leaves the compiler no
+    // other choice): the compaction and the LDS deltas below run meanwhile.  (Non-DEFER form: the stores below go out next.)
+    if (P.sig && !dead && lane < 2) {
+        if (lane ? right : left) sig_set_pair(P.sig, P.sig_stride, tile, lane ? yb_pairkey(c, R) : yb_pairkey(L, c));
+    }
     // ---- compaction in registers
     const int D0 = dead ? p : p + 1; // first slot that leaves
     const int s = dead ? 3 : 1;      // how many leave (contiguous)
@@ -987,14 +991,6 @@ __device__ __forceinline__ void single_site_tile(SlowCtx<AggV> &C, uint32_t tile
         if (lane == 0) P.tile_len[tile] = new_len;
     }
     YB_SS_STAMP(4);
-    // the two pairs this site creates are now present in the tile: one signature word each, set by lanes 0 and 1
-#ifdef YB_DBG_NOSIGSET
-    if (false) {
-#else
-    if (P.sig && !dead && lane < 2) {
-#endif
-        if (lane ? right : left) sig_set_pair(P.sig, P.sig_stride, tile, lane ? yb_pairkey(c, R) : yb_pairkey(L, c));
-    }
     YB_SS_STAMP(3);
     // ---- deltas (tile_logic.h with no neighbouring site): (L,a)-1 (L,c)+1 (b,R)-1 (c,R)+1, one per lane: the four
     // aggregator probes run side by side instead of one after the other
