@@ -2966,7 +2966,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
     using AggV = typename std::conditional<WEIGHTED, unsigned long long, int>::type;
     constexpr int NT = NW * 64;                   // threads of the workgroup (NW waves)
     constexpr int KTM = scan_kt_max(NW);
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_n, s_claim;             // entries on the hit list; the next one no wave has taken yet
     __shared__ uint2 s_list[NT * KTM];            // (tile, live length | merges noted << 16)
     __shared__ uint32_t s_keys[AGG_N];
     __shared__ AggV s_vals[AGG_N];
@@ -2996,7 +2996,10 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
         agg_init(Agg<AggV>{s_keys, s_vals, P.agg_mask}, NT);
         wave_lds_init(s_w[wib], lane);
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_claim = (uint32_t)NW; // (entries 0 .. NW-1 are the waves' first ones)
+        }
     }
     if (st_stop) return false; // (the same answer in every workgroup: nobody takes a ticket)
     YB_SCAN_STAMP(5); // (profile build: the batch has arrived)
@@ -3021,7 +3024,8 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
     WaveLds &W = s_w[wib];
     __syncthreads();
     YB_SCAN_STAMP(6); // (profile build: LDS tables initialised)
-    unsigned long long n_read = 0, wave_sites = 0, wave_freed = 0;
+    uint32_t n_read = 0; // (tiles this workgroup read in this launch: fits easily)
+    unsigned long long wave_sites = 0, wave_freed = 0;
     const uint32_t kt = Q.kt;
     const uint32_t chunk = Q.chunk;
     const uint32_t n_chunks = (P.n_tiles + chunk - 1) / chunk;
@@ -3036,14 +3040,28 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
             km[j] = 0;
             if (j < kt && t < t_end) len[j] = P.tile_len[t]; // (t_end: the end of this workgroup's run of tiles, or of the stream)
         }
-#pragma unroll 2
-        for (uint32_t k = 0; k < nbatch; ++k) {
-            const unsigned long long *rowp = P.sig + (size_t)s_bm.row[k] * P.sig_stride;
-            const unsigned long long mask = s_bm.mask[k];
+        // (KG merges' words in flight at a time -- 16 loads per thread: ONE trip to memory for a batch of up to KG instead of one per
+        // two merges; the registers are free here, the rewrite is what sets the kernel's count)
+        constexpr uint32_t KG = KTM >= 4 ? 4u : 8u;
+        for (uint32_t k0 = 0; k0 < nbatch; k0 += KG) {
+            unsigned long long w[KG][KTM];
 #pragma unroll
-            for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
-                const uint32_t t = ch * chunk + j * NT + threadIdx.x;
-                if (j < kt && t < t_end && (rowp[t] & mask) == mask) km[j] |= 1u << k;
+            for (uint32_t kk = 0; kk < KG; ++kk) {
+                const bool on = k0 + kk < nbatch; // uniform
+                const unsigned long long *rowp = P.sig + (size_t)s_bm.row[(k0 + kk) & (uint32_t)(KMAX - 1)] * P.sig_stride;
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)KTM; ++j) {
+                    const uint32_t t = ch * chunk + j * NT + threadIdx.x;
+                    w[kk][j] = (on && j < kt && t < t_end) ? rowp[t] : 0ull;
+                }
+            }
+#pragma unroll
+            for (uint32_t kk = 0; kk < KG; ++kk) {
+                const unsigned long long mask = s_bm.mask[(k0 + kk) & (uint32_t)(KMAX - 1)];
+                const bool on = k0 + kk < nbatch;
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)KTM; ++j)
+                    if (on && (w[kk][j] & mask) == mask) km[j] |= 1u << (k0 + kk);
             }
         }
         YB_SCAN_STAMP(1);
@@ -3080,7 +3098,16 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
             if (gB + 8u > fc_ && gB < pad_end) wb[64 + lane] = t.vb;
             if (lane == 0) P.tile_len[tile_] = len_;
         };
-        uint32_t j = wib;
+        // the next entry nobody has taken (tiles differ a lot in what they cost -- a tile that passed the signature test without
+        // holding the pair is dropped after the match: dealt out by turns, the waves of a workgroup finish far apart).  Claimed at
+        // the END of a tile's turn, where registers are free.
+        auto claim = [&]() -> uint32_t {
+            uint32_t nx = 0;
+            if (lane == 0) nx = atomicAdd(&s_claim, 1u);
+            return __builtin_amdgcn_readfirstlane(nx);
+        };
+        uint32_t j = wib;                // the entry whose tile is in q0
+        uint32_t jn = j < n ? claim() : n; // the one after it
         uint2 it0 = j < n ? list_at(j) : make_uint2(0u, 0u);
         TileRegs q0 = load_tile(P.tiles, it0.x, it0.y & 0xffffu, lane);
         while (j < n) {
@@ -3093,7 +3120,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
                 pend_fc = CAP;
             }
             asm volatile("" ::: "memory"); // (the stores stay here: their registers are free for the next prefetch)
-            j += NW;
+            j = jn;
             if (j < n) { // (one candidate ahead: a second one in flight cost the flat form its fourth wave per SIMD)
                 it0 = list_at(j);
                 q0 = load_tile(P.tiles, it0.x, it0.y & 0xffffu, lane);
@@ -3142,6 +3169,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
             pend_len = tlen;
             pend_fc = first_changed;
             (void)len_in;
+            if (j < n) jn = claim();
         }
         if (pend_fc < (uint32_t)CAP) write_back(pend, pend_tile, pend_len, pend_fc);
         __syncthreads();
@@ -3149,7 +3177,15 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
 #ifdef YB_PROFILE_SCAN
         if (threadIdx.x == 0 && blockIdx.x < MAX_LISTS_PROF) g_scan_prof[blockIdx.x * 8 + 3] = ((unsigned long long)nbatch << 32) | n; // (merges of this launch, candidate tiles of this workgroup)
 #endif
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) {
+            // (the two constants are made here: hoisted out of the loop they sat in registers through all of it -- and were the two
+            // the 16-wave form had to spill)
+            uint32_t zero, first;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(first) : "n"(NW));
+            s_n = zero;
+            s_claim = first;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0 && Q.blk_read) Q.blk_read[blockIdx.x] += n_read;
