@@ -3161,7 +3161,7 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
                     }
 #endif
                 } else {
-                    slow_tile<WEIGHTED, AggV, false, false, true>(C, W, tile, tlen, r, na, nb, wave_sites, wave_freed, first_changed);
+                    slow_tile<WEIGHTED, AggV, false, true, true>(C, W, tile, tlen, r, na, nb, wave_sites, wave_freed, first_changed, mine & 0xffu, mine >> 8); // (the masks are at hand)
                 }
             }
             // to be written back, if anything changed (see above; assigned on every path: the registers of the tile before are dead
