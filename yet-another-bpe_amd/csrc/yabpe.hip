@@ -1391,7 +1391,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             int64_t wpb_opt = optv(c, "full_wpb", 0);
             if (wpb_opt <= 0)
                 wpb_opt = (c->st_host->best_count <= (unsigned long long)optv(c, "wide_sites_per_cu", 20) * c->n_cu && (c->n_tiles + 2047u) / 2048u <= c->n_cu) ? 16 : 8;
-            const uint32_t nw = wpb_opt >= 16 ? 16u : wpb_opt >= 8 ? 8u : (uint32_t)WPB;
+            const uint32_t nw = wpb_opt >= 16 ? 16u : 8u;  // (a 4-wave form existed until round 3: never chosen, pruned)
             const uint32_t nt = nw * 64u;
             const uint32_t target = (uint32_t)std::max<int64_t>(1, optv(c, "full_skip_blocks", (int64_t)c->n_cu * (16 / nw)));
             // tiles per workgroup: what fills `target` workgroups, in whole waves of signature tests, at most kt_max per thread
@@ -1420,8 +1420,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
             hipLaunchKernelGGL((k_scan_skip<false, NW_>), dim3(grid), dim3(NW_ * 64), 0, c->stream, c->st, SQ);     \
     } while (0)
             if (nw == 16) YB_LAUNCH_SPARSE(16);
-            else if (nw == 8) YB_LAUNCH_SPARSE(8);
-            else YB_LAUNCH_SPARSE(WPB);
+            else YB_LAUNCH_SPARSE(8);
 #undef YB_LAUNCH_SPARSE
             c->scan_skip_launches++;
             if (ev) HIPCHK(c, hipEventRecord(ev->e1, c->stream));

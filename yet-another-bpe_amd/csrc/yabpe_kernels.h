@@ -3200,8 +3200,8 @@ __device__ __forceinline__ bool scan_skip_block(DevState *st, const ScanSkipPara
 // st (= Q.A.st) is a kernel argument of its own, the FIRST one: the library is built with kernel-argument preload for two
 // dwords (Makefile), so the pointer is in SGPRs when the wave starts and the read of the batch record does not have to wait
 // for the argument segment first -- one dependent trip less in front of every launch.
-template <bool WEIGHTED, int NW = WPB>
-__global__ __launch_bounds__(NW * 64, NW == WPB ? 3 : 16 / NW) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (<= 128 VGPRs, 16 waves per CU)
+template <bool WEIGHTED, int NW>
+__global__ __launch_bounds__(NW * 64, 16 / NW) void k_scan_skip(DevState *st, ScanSkipParams Q) { // (NW = 8 or 16; <= 128 VGPRs, 16 waves per CU)
     __shared__ WinEnt s_selwin[WIN];
     if (!scan_skip_block<WEIGHTED, NW>(st, Q)) return;
     fused_select_tail(Q.F, s_selwin);
