@@ -194,7 +194,8 @@ def main() -> None:
                    "table_capacity": st["table_capacity"], "table_rebuilds": st["table_rebuilds"], "long_words": st["n_long_words"]},
     }
     if world > 1:
-        out["exchange"] = {"all_gathers": st["exchanges"], "bytes_received_per_merge": st["exchange_bytes"], "record_capacity_per_rank": st["exchange_cap_records"],
+        out["exchange"] = {"exchanges": st["exchanges"], "window_bytes_per_exchange": st["exchange_bytes"],  # ([header | records transmitted at most] x ranks: what an all-gather moves; a peer-to-peer push carries only the records produced)
+                           "record_capacity_per_rank": st["exchange_cap_records"],
                            "buffer_growths": st["exchange_growths"], "max_records_of_a_rank_at_a_batch_end": st["exchange_max_records"],
                            "merges_per_exchange": round(n_merges / max(1, st["exchanges"]), 2),
                            "peer_to_peer": bool(st["exchange_p2p"]),
