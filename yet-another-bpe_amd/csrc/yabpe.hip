@@ -1349,11 +1349,13 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
     }
     // the long words (more than 63 tokens: outside the tile stream) ride on the fused launch as extra workgroups, like the
     // lexrank maintenance: one signature word per long word and merge, the few words that pass are rewritten
-    const LongParams LW{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride};
+    // (words per workgroup: about two workgroups per CU while there are few long words, BLOCK when there are many)
+    const uint32_t long_group = (uint32_t)std::min<uint64_t>(BLOCK, std::max<uint64_t>(32, cdiv64(c->n_long, 2ull * std::max(1, c->n_cu))));
+    const LongParams LW{c->long_tok, c->long_off, c->long_len, c->long_freq, c->n_long, out_table, c->st, c->long_sig, c->long_sig_stride, long_group};
     const bool long_rides = fuse_kernel && c->n_long && c->n_tiles && rank_rides;
-    const uint32_t long_blocks = long_rides ? cdiv64(c->n_long, BLOCK) : 0u;
+    const uint32_t long_blocks = long_rides ? cdiv64(c->n_long, long_group) : 0u;
     if (fuse_kernel && c->n_long && !long_rides)  // (no tile launch to ride on: on their own, first -- the fused launch must be the last one to touch the table)
-        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, LW);
+        hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, long_group)), dim3(BLOCK), 0, c->stream, LW);
     // the fused selection folds the per-workgroup counters of THIS launch too: it must know the larger grid
     auto fuse_params = [&](uint32_t grid_now) {
         FuseParams F{};
@@ -1429,7 +1431,7 @@ static int launch_apply(yabpe_ctx *c, uint32_t rec_base, uint32_t tokens_upper, 
         HIPCHK(c, hipEventRecord(ev->e1, c->stream));
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->e2, c->stream));
-    if (!fuse_kernel && c->n_long) hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, BLOCK)), dim3(BLOCK), 0, c->stream, LW);
+    if (!fuse_kernel && c->n_long) hipLaunchKernelGGL(k_apply_long, dim3(cdiv64(c->n_long, long_group)), dim3(BLOCK), 0, c->stream, LW);
     if (c->multi) {
         // Per batch: the apply launch above left this rank's updates as [header | records] in its send buffer (the
         // aggregator flush writes them there: no delta table, no extraction pass); ONE all-gather; ONE launch adds every

@@ -1463,6 +1463,8 @@ struct LongParams {
     DevState *st;
     unsigned long long *sig; // per-word signatures, same blocked Bloom filter and layout as the tiles' (sig[row * stride + word]); may be NULL
     uint32_t sig_stride;
+    uint32_t group;          // words per workgroup of apply_long_block (0: BLOCK).  Few long words: small groups, so that the words a
+                             // merge hits are rewritten by many workgroups side by side and not by a handful one after the other
 };
 
 __global__ __launch_bounds__(BLOCK) void k_count_long(LongParams P) {
@@ -1510,8 +1512,9 @@ __device__ __forceinline__ void apply_long_block(const LongParams &P, uint32_t b
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     {
-        const uint32_t i = block * BLOCK + threadIdx.x;
-        bool maybe = i < P.n_long;
+        const uint32_t group = P.group ? min(P.group, (uint32_t)BLOCK) : (uint32_t)BLOCK;
+        const uint32_t i = block * group + threadIdx.x;
+        bool maybe = threadIdx.x < group && i < P.n_long;
         if (maybe && P.sig) {
             const SigHash H = sig_hash(self);
             maybe = (P.sig[(size_t)H.row * P.sig_stride + i] & H.mask) == H.mask;
